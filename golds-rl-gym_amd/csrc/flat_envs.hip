@@ -1,0 +1,423 @@
+// Solow-v0 and TradeAR1-v0 on gfx950 (reference fed_gym/envs/fed_env.py:161-334), with the worker
+// loop body of fed_gym/agents/paac/emulator_runner.py:48-65 (step, auto-reset, process_state,
+// history window) fused into the same launch.
+//
+// Mapping: one env per lane, state as float32 struct-of-arrays ([feature][env]) so every load
+// and store of a wave is one contiguous 256-B segment.  Both kernels are HBM/latency bound
+// (Solow ~53 B, TradeAR1-16 ~481 B per env-step).  Finished episodes are compacted with a wave
+// ballot + one atomic per wave into done_list for the follow-up pass that refills Solow's
+// shock tape.
+#include "common.h"
+#include "rng.h"
+
+namespace grl {
+
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void compact_done(bool done, int env, int32_t *done_list, int32_t *done_count) {
+    unsigned long long m = __ballot(done);
+    if (m == 0) return;
+    int lane = threadIdx.x & 63;
+    int leader = __ffsll((long long)m) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(done_count, __popcll(m));
+    base = __shfl(base, leader);
+    if (done) done_list[base + __popcll(m & ((1ull << lane) - 1ull))] = env;
+}
+
+// ------------------------------------------------------------------------------------------ Solow
+struct SolowParams {
+    float *k, *z, *e, *z0, *tape;
+    int32_t *tape_pos, *nhist, *elapsed, *episode;
+    const float *actions;
+    float *reward;
+    uint8_t *done;
+    float *obs_raw, *obs, *history;
+    int32_t *done_list, *done_count, *err_flag;
+    const int32_t *reset_list, *reset_count;
+    int E, P, Q, T, rnn, max_steps;
+    float rho_z[8], rho_e[8];
+    float delta, sigma, kss;
+    uint32_t flags, env_off;
+    uint64_t seed;
+};
+
+// SolowStateProcessor: obs / [100, 1] (state_processors.py:69-71) and the history window as the
+// worker builds it (quirk Q11: min(n,rnn) copies of the CURRENT state, zero padded at the end)
+__device__ __forceinline__ void solow_write_obs(const SolowParams &S, int env, float k, float zl, int nh) {
+    reinterpret_cast<float2 *>(S.obs_raw)[env] = make_float2(k, zl);
+    float2 o = make_float2(k / 100.0f, zl);
+    reinterpret_cast<float2 *>(S.obs)[env] = o;
+    int n = nh < S.rnn ? nh : S.rnn;
+    for (int r = 0; r < S.rnn; ++r)
+        reinterpret_cast<float2 *>(S.history)[(size_t)env * S.rnn + r] = r < n ? o : make_float2(0.f, 0.f);
+}
+
+// SolowEnv._reset without the tape (fed_env.py:242-250): k = k_ss(0.33), e = 0, z ~ N(0, sigma)^p
+__device__ __forceinline__ float solow_reset_env(const SolowParams &S, int env) {
+    S.k[env] = S.kss;
+    for (int i = 0; i < S.Q; ++i) S.e[(size_t)i * S.E + env] = 0.f;
+    const bool fixed = S.flags & (GRL_F_RESET_FROM_SNAPSHOT | GRL_F_RESEED_EACH_RESET);
+    float zl = 0.f;
+    if (fixed && (S.flags & GRL_F_RESET_FROM_SNAPSHOT)) {
+        for (int i = 0; i < S.P; ++i) { zl = S.z0[(size_t)i * S.E + env]; S.z[(size_t)i * S.E + env] = zl; }
+    } else {
+        uint32_t ep = (S.flags & GRL_F_RESEED_EACH_RESET) ? 0u : (uint32_t)S.episode[env];
+        for (int i = 0; i < S.P; i += 2) {
+            double n0, n1;
+            normal_pair(rng_block(S.seed, (uint32_t)env + S.env_off, ep, RS_SOLOW_Z0, i >> 1), n0, n1);
+            zl = (float)((double)S.sigma * n0);
+            S.z[(size_t)i * S.E + env] = zl;
+            if (i + 1 < S.P) { zl = (float)((double)S.sigma * n1); S.z[(size_t)(i + 1) * S.E + env] = zl; }
+        }
+    }
+    S.tape_pos[env] = S.T - 1;
+    S.elapsed[env] = 0;
+    S.nhist[env] = 1;            // histories[i] = [reset state]  (emulator_runner.py:52)
+    S.episode[env] = S.episode[env] + 1;
+    return zl;
+}
+
+__global__ __launch_bounds__(256) void solow_step_kernel(SolowParams S) {
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    bool done = false;
+    if (env < S.E) {
+        // SolowEnv._step (fed_env.py:201-236)
+        float s = fmaxf(1e-3f, S.actions[env]);
+        float k = S.k[env];
+        float zl = S.z[(size_t)(S.P - 1) * S.E + env];
+        float y = expf(zl) * powf(k, 0.33f);
+        float kn = (1.0f - S.delta) * k + s * y;
+        int pos = S.tape_pos[env];
+        float e_t = 0.f;
+        if (pos >= 0) e_t = S.tape[(size_t)pos * S.E + env];   // es.pop(): from the end (quirk Q8)
+        else atomicAdd(S.err_flag, 1);                          // reference: IndexError, pop from empty list
+        S.tape_pos[env] = pos - 1;
+        float ar = 0.f, ma = 0.f;
+        for (int i = 0; i < S.P; ++i) ar += S.rho_z[i] * S.z[(size_t)i * S.E + env];
+        for (int i = 0; i < S.Q; ++i) ma += S.rho_e[i] * S.e[(size_t)i * S.E + env];
+        float zn = (ar + ma) + e_t;
+        for (int i = 0; i + 1 < S.P; ++i) S.z[(size_t)i * S.E + env] = S.z[(size_t)(i + 1) * S.E + env];
+        S.z[(size_t)(S.P - 1) * S.E + env] = zn;
+        for (int i = 0; i + 1 < S.Q; ++i) S.e[(size_t)i * S.E + env] = S.e[(size_t)(i + 1) * S.E + env];
+        S.e[(size_t)(S.Q - 1) * S.E + env] = e_t;
+        S.k[env] = kn;
+        S.reward[env] = logf((1.0f - s) * y + 1e-4f);
+        int el = S.elapsed[env] + 1;
+        done = S.max_steps > 0 && el >= S.max_steps;    // Solow itself never ends (fed_env.py:234)
+        S.done[env] = done ? 1 : 0;
+        int nh;
+        if (done) {   // auto-reset: terminal reward stays, observation is the reset one (quirk Q6)
+            zn = solow_reset_env(S, env);
+            kn = S.kss;
+            nh = 1;
+        } else {
+            S.elapsed[env] = el;
+            nh = S.nhist[env] + 1;
+            if (nh > S.rnn + 1) nh = S.rnn + 1;           // list is trimmed to rnn+1 (emulator_runner.py:61)
+            S.nhist[env] = nh;
+        }
+        solow_write_obs(S, env, kn, zn, nh);
+    }
+    compact_done(done, env, S.done_list, S.done_count);
+}
+
+// explicit reset of the listed envs (gym reset()): light part; the tape is refilled by the next kernel
+__global__ __launch_bounds__(256) void solow_reset_kernel(SolowParams S) {
+    const int li = blockIdx.x * blockDim.x + threadIdx.x;
+    if (li >= *S.reset_count) return;
+    int env = S.reset_list[li];
+    float zl = solow_reset_env(S, env);
+    S.nhist[env] = 0;   // an explicit reset happens in the learner; the worker's list starts empty (emulator_runner.py:23)
+    solow_write_obs(S, env, S.kss, zl, 1);
+}
+
+// es = N(0, sigma)^T for every env in the list (fed_env.py:248); episode[env] was already advanced
+__global__ __launch_bounds__(256) void solow_tape_kernel(SolowParams S) {
+    const int n = *S.reset_count;
+    const long long total = (long long)n * (S.T / 2);
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        int li = (int)(idx % n);
+        int pr = (int)(idx / n);
+        int env = S.reset_list[li];
+        uint32_t ep = (S.flags & GRL_F_RESEED_EACH_RESET) ? 0u : (uint32_t)(S.episode[env] - 1);
+        double n0, n1;
+        normal_pair(rng_block(S.seed, (uint32_t)env + S.env_off, ep, RS_SOLOW_TAPE, pr), n0, n1);
+        S.tape[(size_t)(2 * pr) * S.E + env] = (float)((double)S.sigma * n0);
+        S.tape[(size_t)(2 * pr + 1) * S.E + env] = (float)((double)S.sigma * n1);
+    }
+}
+
+__global__ void solow_observe_kernel(SolowParams S) {
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= S.E) return;
+    solow_write_obs(S, env, S.k[env], S.z[(size_t)(S.P - 1) * S.E + env], S.nhist[env] < 1 ? 1 : S.nhist[env]);
+}
+
+static SolowParams solow_params(grl_handle *h) {
+    SolowParams S{};
+    S.k = h->so.k; S.z = h->so.z; S.e = h->so.e; S.z0 = h->so.z0; S.tape = h->so.tape;
+    S.tape_pos = h->so.tape_pos; S.nhist = h->so.nhist; S.elapsed = h->elapsed; S.episode = h->episode;
+    S.reward = h->reward; S.done = h->done; S.obs_raw = h->so.obs_raw; S.obs = h->so.obs; S.history = h->so.history;
+    S.done_list = h->done_list; S.done_count = h->done_count; S.err_flag = h->err_flag;
+    S.E = h->E; S.P = h->so.P; S.Q = h->so.Q; S.T = h->cfg.solow_tape_len; S.rnn = h->cfg.rnn_length;
+    S.max_steps = h->cfg.max_episode_steps;
+    for (int i = 0; i < 8; ++i) { S.rho_z[i] = h->so.rho_z[i]; S.rho_e[i] = h->so.rho_e[i]; }
+    S.delta = (float)h->cfg.solow_delta; S.sigma = (float)h->cfg.solow_sigma;
+    S.kss = (float)pow(0.33 / h->cfg.solow_delta, 1.0 / (1.0 - 0.33));   // _k_ss(0.33) (fed_env.py:198-199,243)
+    S.flags = h->cfg.flags; S.env_off = (uint32_t)h->cfg.env_id_offset; S.seed = h->cfg.seed;
+    return S;
+}
+
+template <typename T>
+static int dmalloc(grl_handle *h, T **p, size_t n) {
+    GRL_HIP(h, hipMalloc((void **)p, n * sizeof(T)));
+    h->allocs.push_back(*p);
+    GRL_HIP(h, hipMemsetAsync(*p, 0, n * sizeof(T), h->stream));
+    return GRL_OK;
+}
+
+int solow_alloc(grl_handle *h) {
+    const grl_config &c = h->cfg;
+    size_t E = h->E;
+    // SolowEnv.__init__ (fed_env.py:179-189).  q == 0 behaves exactly like q == 1 with rho_e = [0.5]
+    // (e starts empty -> MA term 0, then e = [e_t]); p == 0 cannot even reset in the reference
+    // (z[-1] on an empty array) and is rejected by grl_create.
+    h->so.P = c.solow_p;
+    h->so.Q = c.solow_q > 0 ? c.solow_q : 1;
+    double sum = 0;
+    for (int i = 1; i <= c.solow_p; ++i) sum += pow(0.5, i);
+    for (int i = 0; i < 8; ++i) { h->so.rho_z[i] = 0.f; h->so.rho_e[i] = 0.f; }
+    for (int i = 1; i <= c.solow_p; ++i) h->so.rho_z[i - 1] = (float)(pow(0.5, i) / (sum / 0.95));
+    for (int i = 1; i <= h->so.Q; ++i) h->so.rho_e[i - 1] = (float)pow(0.5, i);
+    int rc;
+    if ((rc = dmalloc(h, &h->so.k, E))) return rc;
+    if ((rc = dmalloc(h, &h->so.z, E * h->so.P))) return rc;
+    if ((rc = dmalloc(h, &h->so.z0, E * h->so.P))) return rc;
+    if ((rc = dmalloc(h, &h->so.e, E * h->so.Q))) return rc;
+    if ((rc = dmalloc(h, &h->so.tape, E * (size_t)c.solow_tape_len))) return rc;
+    if ((rc = dmalloc(h, &h->so.tape_pos, E))) return rc;
+    if ((rc = dmalloc(h, &h->so.nhist, E))) return rc;
+    if ((rc = dmalloc(h, &h->so.obs_raw, E * 2))) return rc;
+    if ((rc = dmalloc(h, &h->so.obs, E * 2))) return rc;
+    if ((rc = dmalloc(h, &h->so.history, E * c.rnn_length * 2))) return rc;
+    return GRL_OK;
+}
+
+static bool solow_needs_tape(const grl_handle *h) {
+    return !(h->cfg.flags & GRL_F_RESET_FROM_SNAPSHOT);
+}
+
+int solow_launch_step(grl_handle *h, const float *actions_dev) {
+    SolowParams S = solow_params(h);
+    S.actions = actions_dev;
+    GRL_HIP(h, hipMemsetAsync(h->done_count, 0, sizeof(int32_t), h->stream));
+    hipLaunchKernelGGL(solow_step_kernel, dim3((h->E + 255) / 256), dim3(256), 0, h->stream, S);
+    GRL_HIP(h, hipGetLastError());
+    if (solow_needs_tape(h) && h->cfg.max_episode_steps > 0) {
+        S.reset_list = h->done_list; S.reset_count = h->done_count;
+        hipLaunchKernelGGL(solow_tape_kernel, dim3(512), dim3(256), 0, h->stream, S);
+        GRL_HIP(h, hipGetLastError());
+    }
+    return GRL_OK;
+}
+
+int solow_launch_reset(grl_handle *h, const int32_t *list_dev, const int32_t *count_dev, int max_count, bool) {
+    SolowParams S = solow_params(h);
+    S.reset_list = list_dev; S.reset_count = count_dev;
+    hipLaunchKernelGGL(solow_reset_kernel, dim3((max_count + 255) / 256), dim3(256), 0, h->stream, S);
+    GRL_HIP(h, hipGetLastError());
+    if (solow_needs_tape(h)) {
+        hipLaunchKernelGGL(solow_tape_kernel, dim3(512), dim3(256), 0, h->stream, S);
+        GRL_HIP(h, hipGetLastError());
+    }
+    return GRL_OK;
+}
+
+int solow_launch_observe(grl_handle *h) {
+    SolowParams S = solow_params(h);
+    hipLaunchKernelGGL(solow_observe_kernel, dim3((h->E + 255) / 256), dim3(256), 0, h->stream, S);
+    GRL_HIP(h, hipGetLastError());
+    return GRL_OK;
+}
+
+// ------------------------------------------------------------------------------------------ TradeAR1
+struct TradeParams {
+    float *cash, *assets, *q, *p;
+    const float *normals;
+    uint32_t *nstep;
+    int32_t *elapsed, *episode;
+    const float *actions;
+    float *reward;
+    uint8_t *done;
+    float *obs_raw, *obs;
+    int32_t *done_list, *done_count, *err_flag;
+    const int32_t *reset_list, *reset_count;
+    int E, n, max_steps;
+    float std_e;
+    uint32_t flags, env_off;
+    uint64_t seed;
+};
+
+// TradeWorker.process_state as it behaves (a3c/worker.py:420-431, quirk Q10):
+// [log(cash+1e-4), log(q+1)..., log(p+1)...]
+__device__ __forceinline__ float trade_proc(int idx, float v) { return idx == 0 ? logf(v + 1e-4f) : logf(v + 1.0f); }
+
+__global__ __launch_bounds__(256) void trade_step_kernel(TradeParams R) {
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    bool done = false;
+    if (env < R.E) {
+        const int n = R.n, S = 1 + 2 * n;
+        const size_t E = R.E;
+        // TradeAR1Env._step (fed_env.py:300-321)
+        float cash = R.cash[env], assets_old = R.assets[env];
+        float cost = 0.f, value = 0.f;
+        bool bad = false;
+        for (int a = 0; a < n; ++a) {
+            float act = R.actions[(size_t)env * n + a];
+            bad |= !(act >= -1.0f && act <= 1.0f);                       // action_space.contains (fed_env.py:301)
+            float p = R.p[a * E + env], q = R.q[a * E + env];
+            float q_add = act > 0.f ? (act / (float)n) * cash / p : act * q;
+            q += q_add;
+            cost += q_add * p;
+            value += q * p;
+            R.q[a * E + env] = q;
+        }
+        if (bad) atomicAdd(R.err_flag, 1);
+        cash = cash + (-cost);
+        float assets = cash + value;
+        bool own_done = assets < 1.0f;                                   // MIN_CASH (fed_env.py:272,313)
+        R.reward[env] = (float)(log((double)assets + 1e-4) - log((double)assets_old + 1e-4));
+        int el = R.elapsed[env] + 1;
+        done = own_done || (R.max_steps > 0 && el >= R.max_steps);
+        R.done[env] = done ? 1 : 0;
+        uint32_t st = R.nstep[env];
+        R.nstep[env] = st + 1;
+        float *oraw = R.obs_raw + (size_t)env * S, *o = R.obs + (size_t)env * S;
+        if (done) {   // auto-reset (emulator_runner.py:50-52) -> TradeAR1Env._reset (fed_env.py:323-330)
+            cash = 10.f;
+            R.assets[env] = 10.f;
+            R.elapsed[env] = 0;
+            R.episode[env] = R.episode[env] + 1;
+            for (int a = 0; a < n; ++a) {
+                R.q[a * E + env] = 0.f; R.p[a * E + env] = 1.f;
+                oraw[1 + a] = 0.f; oraw[1 + n + a] = 1.f;
+                o[1 + a] = trade_proc(1, 0.f); o[1 + n + a] = trade_proc(1, 1.f);
+            }
+        } else {
+            R.assets[env] = assets;
+            R.elapsed[env] = el;
+            const int pairs = (n + 1) / 2;
+            for (int a = 0; a < n; a += 2) {
+                double z0, z1;
+                if (R.flags & GRL_F_INJECT_NOISE) {
+                    z0 = R.normals[a * E + env];
+                    z1 = a + 1 < n ? R.normals[(a + 1) * E + env] : 0.0;
+                } else {
+                    normal_pair(rng_block(R.seed, (uint32_t)env + R.env_off, 0u, RS_TRADE_PRICE, st * pairs + (a >> 1)), z0, z1);
+                }
+                // _price_transition: p**rho_p * exp(std_e * N(0,1))  (fed_env.py:296-298)
+                float p = R.p[a * E + env];
+                p = powf(p, 0.9f) * expf(R.std_e * (float)z0);
+                R.p[a * E + env] = p;
+                float q = R.q[a * E + env];
+                oraw[1 + a] = q; oraw[1 + n + a] = p;
+                o[1 + a] = trade_proc(1, q); o[1 + n + a] = trade_proc(1, p);
+                if (a + 1 < n) {
+                    float p1 = R.p[(a + 1) * E + env];
+                    p1 = powf(p1, 0.9f) * expf(R.std_e * (float)z1);
+                    R.p[(a + 1) * E + env] = p1;
+                    float q1 = R.q[(a + 1) * E + env];
+                    oraw[2 + a] = q1; oraw[2 + n + a] = p1;
+                    o[2 + a] = trade_proc(1, q1); o[2 + n + a] = trade_proc(1, p1);
+                }
+            }
+        }
+        R.cash[env] = cash;
+        oraw[0] = cash;
+        o[0] = trade_proc(0, cash);
+    }
+    compact_done(done, env, R.done_list, R.done_count);
+}
+
+__global__ void trade_reset_kernel(TradeParams R) {
+    const int li = blockIdx.x * blockDim.x + threadIdx.x;
+    if (li >= *R.reset_count) return;
+    const int env = R.reset_list[li];
+    const int n = R.n, S = 1 + 2 * n;
+    const size_t E = R.E;
+    R.cash[env] = 10.f; R.assets[env] = 10.f; R.elapsed[env] = 0; R.episode[env] = R.episode[env] + 1;
+    float *oraw = R.obs_raw + (size_t)env * S, *o = R.obs + (size_t)env * S;
+    oraw[0] = 10.f; o[0] = trade_proc(0, 10.f);
+    for (int a = 0; a < n; ++a) {
+        R.q[a * E + env] = 0.f; R.p[a * E + env] = 1.f;
+        oraw[1 + a] = 0.f; oraw[1 + n + a] = 1.f;
+        o[1 + a] = trade_proc(1, 0.f); o[1 + n + a] = trade_proc(1, 1.f);
+    }
+}
+
+__global__ void trade_observe_kernel(TradeParams R) {
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= R.E) return;
+    const int n = R.n, S = 1 + 2 * n;
+    const size_t E = R.E;
+    float *oraw = R.obs_raw + (size_t)env * S, *o = R.obs + (size_t)env * S;
+    float cash = R.cash[env];
+    oraw[0] = cash; o[0] = trade_proc(0, cash);
+    for (int a = 0; a < n; ++a) {
+        float q = R.q[a * E + env], p = R.p[a * E + env];
+        oraw[1 + a] = q; oraw[1 + n + a] = p;
+        o[1 + a] = trade_proc(1, q); o[1 + n + a] = trade_proc(1, p);
+    }
+}
+
+static TradeParams trade_params(grl_handle *h) {
+    TradeParams R{};
+    R.cash = h->tr.cash; R.assets = h->tr.assets; R.q = h->tr.q; R.p = h->tr.p; R.normals = h->tr.normals;
+    R.nstep = h->tr.nstep; R.elapsed = h->elapsed; R.episode = h->episode; R.reward = h->reward; R.done = h->done;
+    R.obs_raw = h->tr.obs_raw; R.obs = h->tr.obs; R.done_list = h->done_list; R.done_count = h->done_count;
+    R.err_flag = h->err_flag; R.E = h->E; R.n = h->cfg.n_assets; R.max_steps = h->cfg.max_episode_steps;
+    R.std_e = h->tr.std_e; R.flags = h->cfg.flags; R.env_off = (uint32_t)h->cfg.env_id_offset; R.seed = h->cfg.seed;
+    return R;
+}
+
+int trade_alloc(grl_handle *h) {
+    size_t E = h->E, n = h->cfg.n_assets;
+    double sp = h->cfg.trade_std_p;
+    h->tr.std_e = (float)sqrt((sp * sp) * (1 - 0.9 * 0.9));   // fed_env.py:277-278
+    int rc;
+    if ((rc = dmalloc(h, &h->tr.cash, E))) return rc;
+    if ((rc = dmalloc(h, &h->tr.assets, E))) return rc;
+    if ((rc = dmalloc(h, &h->tr.q, E * n))) return rc;
+    if ((rc = dmalloc(h, &h->tr.p, E * n))) return rc;
+    if ((rc = dmalloc(h, &h->tr.normals, E * n))) return rc;
+    if ((rc = dmalloc(h, &h->tr.nstep, E))) return rc;
+    if ((rc = dmalloc(h, &h->tr.obs_raw, E * (1 + 2 * n)))) return rc;
+    if ((rc = dmalloc(h, &h->tr.obs, E * (1 + 2 * n)))) return rc;
+    return GRL_OK;
+}
+
+int trade_launch_step(grl_handle *h, const float *actions_dev) {
+    TradeParams R = trade_params(h);
+    R.actions = actions_dev;
+    GRL_HIP(h, hipMemsetAsync(h->done_count, 0, sizeof(int32_t), h->stream));
+    hipLaunchKernelGGL(trade_step_kernel, dim3((h->E + 255) / 256), dim3(256), 0, h->stream, R);
+    GRL_HIP(h, hipGetLastError());
+    return GRL_OK;
+}
+
+int trade_launch_reset(grl_handle *h, const int32_t *list_dev, const int32_t *count_dev, int max_count) {
+    TradeParams R = trade_params(h);
+    R.reset_list = list_dev; R.reset_count = count_dev;
+    hipLaunchKernelGGL(trade_reset_kernel, dim3((max_count + 255) / 256), dim3(256), 0, h->stream, R);
+    GRL_HIP(h, hipGetLastError());
+    return GRL_OK;
+}
+
+int trade_launch_observe(grl_handle *h) {
+    TradeParams R = trade_params(h);
+    hipLaunchKernelGGL(trade_observe_kernel, dim3((h->E + 255) / 256), dim3(256), 0, h->stream, R);
+    GRL_HIP(h, hipGetLastError());
+    return GRL_OK;
+}
+
+}  // namespace grl

@@ -1,0 +1,118 @@
+// Rollout-side math of the PAAC learner on gfx950: n-step return / advantage / GAE
+// (reference fed_gym/agents/paac/paac.py:159-172,360-372; fed_gym/agents/a3c/worker.py:232-239,
+// 284-294), reward clipping (paac/actor_learner.py:91-97), the action transforms
+// (paac/emulator_runner.py:77-79,113-118; a3c/worker.py:17-34,440-442) and Gaussian draws.
+// All are one-pass HBM-bound kernels: 20 B per (t,b) for the returns.
+#include "common.h"
+#include "rng.h"
+
+namespace grl {
+
+// One lane per column b; walks t = T-1..0 with a float64 running return like the reference's
+// float64 numpy arrays, including its one float32 product gamma*V(s_T) (bootstrap value is the
+// net's float32 output; pinned by tests/golden/returns.npz).
+__global__ __launch_bounds__(256) void returns_kernel(const float *__restrict__ r, const float *__restrict__ v,
+                                                      const float *__restrict__ mask, const float *__restrict__ boot,
+                                                      int T, int B, float gamma, float lam, float scale, float clip_lo,
+                                                      float clip_hi, float *__restrict__ y, float *__restrict__ adv) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const bool clip = clip_lo < clip_hi;
+    const double g = (double)gamma;
+    if (lam == 1.0f) {
+        double est = 0.0;
+        for (int t = T - 1; t >= 0; --t) {
+            size_t i = (size_t)t * B + b;
+            float rew = r[i];
+            if (clip) rew = rew > clip_hi ? clip_hi : (rew < clip_lo ? clip_lo : rew);   // rescale_reward
+            double ge = (t == T - 1) ? (double)(gamma * boot[b]) : g * est;
+            if (mask) ge = ge * (double)mask[i];
+            est = (double)rew + ge;
+            y[i] = (float)est;
+            adv[i] = (float)((est - (double)v[i]) / (double)scale);
+        }
+    } else {
+        // GAE: delta_t = r_t + g V_{t+1} - V_t ; A_t = delta_t + g*lam*A_{t+1} ; target = A_t + V_t
+        double run = 0.0, vnext = (double)boot[b];
+        const double gl = g * (double)lam;
+        for (int t = T - 1; t >= 0; --t) {
+            size_t i = (size_t)t * B + b;
+            float rew = r[i];
+            if (clip) rew = rew > clip_hi ? clip_hi : (rew < clip_lo ? clip_lo : rew);
+            double m = mask ? (double)mask[i] : 1.0;
+            double vt = (double)v[i];
+            double delta = (double)rew + g * vnext * m - vt;
+            run = delta + gl * m * run;
+            y[i] = (float)(run + vt);
+            adv[i] = (float)(run / (double)scale);
+            vnext = vt;
+        }
+    }
+}
+
+int launch_returns(grl_handle *h, const float *r, const float *v, const float *mask, const float *boot, int T, int B,
+                   float gamma, float lam, float scale, float clip_lo, float clip_hi, float *y, float *adv) {
+    hipLaunchKernelGGL(returns_kernel, dim3((B + 255) / 256), dim3(256), 0, h->stream, r, v, mask, boot, T, B, gamma, lam,
+                       scale, clip_lo, clip_hi, y, adv);
+    GRL_HIP(h, hipGetLastError());
+    return GRL_OK;
+}
+
+// sigmoid (a3c/worker.py:17-34), tanh (:440-442), Swarm norm clip (emulator_runner.py:113-118)
+__global__ void transform_kernel(int kind, float *a, int rows, int cols) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (kind == GRL_ENV_SWARM) {
+        if (i >= rows) return;
+        float2 q = reinterpret_cast<float2 *>(a)[i];
+        float d = sqrtf(q.x * q.x + q.y * q.y);          // np.linalg.norm(actions, axis=-1)
+        if (d >= 1.0f) { q.x /= d; q.y /= d; }           // MAX_MOVE_NORM = 1
+        reinterpret_cast<float2 *>(a)[i] = q;
+    } else {
+        if (i >= rows * cols) return;
+        float x = a[i];
+        if (kind == GRL_ENV_SOLOW) {
+            float z = expf(-fabsf(x));
+            a[i] = x >= 0.f ? 1.0f / (1.0f + z) : z / (1.0f + z);
+        } else {
+            a[i] = tanhf(x);
+        }
+    }
+}
+
+int launch_transform(grl_handle *h, int kind, float *actions_dev, int rows, int cols) {
+    int n = kind == GRL_ENV_SWARM ? rows : rows * cols;
+    hipLaunchKernelGGL(transform_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, kind, actions_dev, rows, cols);
+    GRL_HIP(h, hipGetLastError());
+    return GRL_OK;
+}
+
+__global__ void randn_kernel(float *dst, size_t n, uint64_t seed, uint32_t rank_off, uint32_t stream, uint64_t counter) {
+    size_t pr = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (2 * pr >= n) return;
+    uint64_t c = counter + pr;
+    double n0, n1;
+    normal_pair(rng_block(seed, rank_off, (uint32_t)(c >> 32), RS_USER + stream, (uint32_t)c), n0, n1);
+    dst[2 * pr] = (float)n0;
+    if (2 * pr + 1 < n) dst[2 * pr + 1] = (float)n1;
+}
+
+int launch_randn(grl_handle *h, float *dst, size_t n, uint32_t stream, uint64_t counter) {
+    size_t pairs = (n + 1) / 2;
+    hipLaunchKernelGGL(randn_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, h->stream, dst, n, h->cfg.seed,
+                       (uint32_t)h->cfg.env_id_offset, stream, counter);
+    GRL_HIP(h, hipGetLastError());
+    return GRL_OK;
+}
+
+__global__ void iota_kernel(int32_t *dst, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = i;
+}
+
+int launch_iota(grl_handle *h, int32_t *dst, int n) {
+    hipLaunchKernelGGL(iota_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, dst, n);
+    GRL_HIP(h, hipGetLastError());
+    return GRL_OK;
+}
+
+}  // namespace grl

@@ -332,16 +332,17 @@ def philox4x32(ctr, key):
     return np.stack(c, axis=-1).astype(np.uint32)
 
 
-def rng_block(seed, env_id, stream, counter):
-    """One Philox block for (seed, global env id, stream, counter): key = seed lo/hi,
-    ctr = (counter, env_id lo, env_id hi, stream).  Broadcasts over arrays."""
+def rng_block(seed, env_id, episode, stream, counter):
+    """One Philox block: key = seed lo/hi, ctr = (counter, global env id, episode, stream).
+    Mirrors golds-rl-gym_amd/csrc/rng.h:rng_block.  Broadcasts over arrays."""
     env_id = np.asarray(env_id, dtype=np.uint64)
     counter = np.asarray(counter, dtype=np.uint64)
-    shape = np.broadcast(env_id, counter).shape
+    episode = np.asarray(episode, dtype=np.uint64)
+    shape = np.broadcast(env_id, counter, episode).shape
     ctr = np.zeros(shape + (4,), dtype=np.uint32)
     ctr[..., 0] = (counter & np.uint64(0xFFFFFFFF)).astype(np.uint32)
     ctr[..., 1] = (env_id & np.uint64(0xFFFFFFFF)).astype(np.uint32)
-    ctr[..., 2] = (env_id >> np.uint64(32)).astype(np.uint32)
+    ctr[..., 2] = (episode & np.uint64(0xFFFFFFFF)).astype(np.uint32)
     ctr[..., 3] = np.uint32(stream)
     key = np.zeros(shape + (2,), dtype=np.uint32)
     key[..., 0] = np.uint32(seed & 0xFFFFFFFF)

@@ -180,7 +180,7 @@ def test_philox_known_answer():
     z = O.philox4x32(np.array([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], np.uint32),
                      np.array([0xa4093822, 0x299f31d0], np.uint32))
     assert [hex(v) for v in z] == ["0xd16cfe09", "0x94fdcceb", "0x5001e420", "0x24126ea1"]
-    u0, u1 = O.u01_pair(O.rng_block(1692, np.arange(1000), 0, 0))
+    u0, u1 = O.u01_pair(O.rng_block(1692, np.arange(1000), 0, 0, 0))
     assert (u0 >= 0).all() and (u0 < 1).all() and abs(u0.mean() - 0.5) < 0.05
-    n0, n1 = O.normal_pair(O.rng_block(1692, np.arange(20000), 1, 3))
+    n0, n1 = O.normal_pair(O.rng_block(1692, np.arange(20000), 0, 1, 3))
     assert abs(n0.mean()) < 0.03 and abs(n1.std() - 1) < 0.03
