@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/s of the PAAC rollout hot path on N MI355X GPUs of one node.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 it is launched by
+torch.distributed.run, one rank per GPU.  Prints ONE JSON line on rank 0.
+
+A "step" is one T=20-step PAAC rollout over this rank's shard of Swarm-v0 envs (BASELINE config 3:
+32 768 envs per GPU, 84x84 observation): per env step -> policy actions, SwarmRunner norm clip,
+SwarmEnv.step, TimeLimit, auto-reset, process_state; then n-step returns/advantages.  Everything
+is resident in HBM when the timed region starts; nothing crosses PCIe inside it.
+
+Envs are independent, so N GPUs shard the env batch (global env ids key the generator, results do
+not depend on N) with no data-path collective: scaling = weak (32 768 envs per GPU).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "golds-rl-gym_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+SWARM_BYTES_PER_ENV_STEP = 4613      # algorithmic HBM bytes of one Swarm env-step
+SWARM_PAIRS_PER_ENV_STEP = 7200      # pair interactions (6400 locust-locust + 800 agent-locust)
+HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--envs", type=int, default=32768, help="Swarm envs per GPU")
+    ap.add_argument("--T", type=int, default=20, help="max_local_steps")
+    ap.add_argument("--policy", default="auto", choices=["auto", "random", "conv"])
+    ap.add_argument("--fast-math", action="store_true", help="GRL_F_SWARM_FAST_MATH (not the parity default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-envs", type=int, default=2048)
+    return ap.parse_args()
+
+
+class RandomPolicyRollout(object):
+    """T-step rollout with a N(0,1) Gaussian policy drawn on the device (SURVEY 8d 'env-only'):
+    actions -> norm clip -> step/auto-reset/observe -> reward capture; then n-step returns."""
+
+    def __init__(self, eng, T, gamma=0.99, scale=1000.0):
+        self.eng, self.T, self.E = eng, T, eng.E
+        E = self.E
+        self.act = eng.dev_alloc(T * E * 20 * 4)
+        self.rew = eng.dev_alloc(T * E * 4)
+        self.val = eng.dev_alloc(T * E * 4)
+        self.boot = eng.dev_alloc(E * 4)
+        self.y = eng.dev_alloc(T * E * 4)
+        self.adv = eng.dev_alloc(T * E * 4)
+        self.gamma, self.scale = gamma, scale
+        self.reward_ptr = eng.out_ptrs().reward
+        self.counter = 0
+
+    def run(self):
+        eng, E, T = self.eng, self.E, self.T
+        for t in range(T):
+            a = self.act + t * E * 20 * 4
+            eng.dev_randn(a, E * 20, 2, self.counter)
+            self.counter += E * 10
+            eng.transform_actions_device(a, E * 10)
+            eng.step_device(a)
+            eng.dev_copy(self.rew + t * E * 4, self.reward_ptr, E * 4)
+        # GridPAACLearner form: unmasked, unclipped, adv/scale (paac.py:360-372)
+        eng.returns_device(self.rew, self.val, None, self.boot, T, E, self.gamma, 1.0, self.scale, 0.0, 0.0, self.y, self.adv)
+
+
+def cpu_baseline(sample_envs, T):
+    """The oracle's C restatement (oracle/oracle_c.c, kind 'port') on the host cores, bounded sample."""
+    from oracle import oracle_c as OC
+    rng = np.random.RandomState(0)
+    E = sample_envs
+    x, xa = rng.rand(E, 80, 2), rng.rand(E, 10, 2)
+    an, pn = rng.normal(size=(E, 10, 2)), rng.normal(size=(E, 80, 2))
+    act = rng.normal(size=(E, 10, 2)).astype(np.float32)
+    OC.swarm_step(x[:64], xa[:64], act[:64], an[:64], pn[:64], threads=1)
+    out = {}
+    ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for label, threads in (("1core", 1), ("allcores", ncores)):
+        xx, xxa = x.copy(), xa.copy()
+        t0 = time.perf_counter()
+        used = 1
+        for t in range(T):
+            xx, xxa, _, _, _, _, used = OC.swarm_step(xx, xxa, act, an, pn, threads=threads)
+        dt = time.perf_counter() - t0
+        out[label] = (E * T / dt, used, dt)
+    v, used, dt = out["allcores"]
+    return {"value": v, "unit": "env-steps/s", "cores": used, "kind": "port",
+            "sample": "oracle/oracle_c.c (SwarmEnv.step + process_state, float64, OpenMP) on %d envs x %d steps, %.1f s; "
+                      "1 core: %.0f env-steps/s" % (E, T, dt + out["1core"][2], out["1core"][0]),
+            "value_1core": out["1core"][0]}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist   # rendezvous/barrier/max only; the data path never touches torch
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+
+    from goldsrl import _ffi
+    from goldsrl import sharding
+    E = args.envs
+    off = sharding.env_id_offset(rank, E)
+    flags = _ffi.F_SWARM_FAST_MATH if args.fast_math else 0
+    eng = _ffi.Engine(_ffi.ENV_SWARM, E, device_id=local_rank, seed=1692, env_id_offset=off, flags=flags)
+    eng.reset()
+
+    policy = "random" if args.policy == "auto" else args.policy
+    if policy == "conv":
+        from goldsrl import rollout as R
+        roll = R.ConvPolicyRollout(eng, args.T)
+    else:
+        roll = RandomPolicyRollout(eng, args.T)
+
+    def barrier():
+        eng.wait()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        roll.run()
+    barrier()
+    eng.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        roll.run()
+    eng.wait()
+    t1 = time.perf_counter()
+    if dist is not None:
+        dist.barrier()
+    launches, kernel_ms = eng.profile_read()
+    eng.profile_enable(False)
+    elapsed = t1 - t0
+    if dist is not None:
+        import torch
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt[0])
+
+    if rank == 0:
+        total_env_steps = world * E * args.T * args.steps
+        value = total_env_steps / elapsed
+        k_avg_ms = kernel_ms / max(launches, 1)
+        achieved = E * SWARM_BYTES_PER_ENV_STEP / (k_avg_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "swarm_step_traffic.json")
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                tj = json.load(f)
+            if tj.get("envs") == E and bool(tj.get("fast_math")) == bool(args.fast_math):
+                traffic = tj.get("hbm_bytes_per_launch")
+        out = {
+            "metric": "env-steps/sec (whole node), 32k parallel Swarm-v0 envs, 20-step PAAC rollout",
+            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "Swarm-v0 84x84, %d envs per GPU, T=%d PAAC rollout (BASELINE configs[2])" % (E, args.T),
+                       "envs_per_gpu": E, "rollout_steps": args.T, "policy": policy,
+                       "swarm_math": "fast" if args.fast_math else "exact",
+                       "stages": "action draw + norm clip + SwarmEnv.step + TimeLimit + auto-reset + process_state + n-step returns"},
+            "roofline": {"bound": "hbm", "kernel": "swarm_kernel<MODE_STEP>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "avg_kernel_ms": k_avg_ms, "launches": launches,
+                         "pair_interactions_per_s": E * SWARM_PAIRS_PER_ENV_STEP / (k_avg_ms * 1e-3),
+                         "note": "kernel is fp64-VALU/transcendental bound (~90 flop/B), not HBM bound: see DESIGN.md"},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample_envs, args.T)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

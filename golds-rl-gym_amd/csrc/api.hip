@@ -21,6 +21,16 @@ int hip_fail(grl_handle *h, hipError_t e, const char *what) {
     return fail(h, GRL_E_HIP, std::string(what) + ": " + hipGetErrorString(e));
 }
 
+void prof_begin(grl_handle *h) {
+    if (!h->prof_on || h->prof_used + 2 > h->prof_ev.size()) return;
+    (void)hipEventRecord(h->prof_ev[h->prof_used], h->stream);
+}
+void prof_end(grl_handle *h) {
+    if (!h->prof_on || h->prof_used + 2 > h->prof_ev.size()) return;
+    (void)hipEventRecord(h->prof_ev[h->prof_used + 1], h->stream);
+    h->prof_used += 2;
+}
+
 struct FieldInfo {
     void *dev;
     size_t elem;      // bytes per element
@@ -146,6 +156,7 @@ int grl_create(const grl_config *cfg, grl_handle **out) {
     h->cfg = *cfg;
     h->E = cfg->num_envs;
     h->step_in_flight = false;
+    h->prof_on = false; h->prof_used = 0;
     h->stream = nullptr; h->ev0 = nullptr; h->ev1 = nullptr;
     h->sw = {}; h->so = {}; h->tr = {};
     int rc = GRL_OK;
@@ -186,6 +197,7 @@ int grl_destroy(grl_handle *h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     for (void *p : h->allocs) hipFree(p);
     for (void *p : h->user_allocs) hipFree(p);
+    for (hipEvent_t ev : h->prof_ev) hipEventDestroy(ev);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -468,6 +480,41 @@ int grl_dev_download(grl_handle *h, void *dst_host, const void *src_dev, size_t 
     hipSetDevice(h->cfg.device_id);
     GRL_HIP(h, hipStreamSynchronize(h->stream));
     GRL_HIP(h, hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));
+    return GRL_OK;
+}
+
+int grl_dev_copy(grl_handle *h, void *dst_dev, const void *src_dev, size_t bytes) {
+    if (!h || !dst_dev || !src_dev) return fail(h, GRL_E_INVALID, "grl_dev_copy: null argument");
+    hipSetDevice(h->cfg.device_id);
+    GRL_HIP(h, hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, h->stream));
+    return GRL_OK;
+}
+
+int grl_profile_enable(grl_handle *h, int32_t on) {
+    if (!h) return GRL_E_INVALID;
+    hipSetDevice(h->cfg.device_id);
+    GRL_HIP(h, hipStreamSynchronize(h->stream));
+    if (on && h->prof_ev.empty()) {
+        h->prof_ev.resize(8192);
+        for (auto &ev : h->prof_ev) GRL_HIP(h, hipEventCreate(&ev));
+    }
+    h->prof_on = on != 0;
+    h->prof_used = 0;
+    return GRL_OK;
+}
+
+int grl_profile_read(grl_handle *h, int32_t *launches_out, float *total_ms_out) {
+    if (!h || !launches_out || !total_ms_out) return GRL_E_INVALID;
+    hipSetDevice(h->cfg.device_id);
+    GRL_HIP(h, hipStreamSynchronize(h->stream));
+    float total = 0.f;
+    for (size_t i = 0; i + 1 < h->prof_used; i += 2) {
+        float ms = 0.f;
+        GRL_HIP(h, hipEventElapsedTime(&ms, h->prof_ev[i], h->prof_ev[i + 1]));
+        total += ms;
+    }
+    *launches_out = (int32_t)(h->prof_used / 2);
+    *total_ms_out = total;
     return GRL_OK;
 }
 

@@ -68,10 +68,17 @@ struct grl_handle {
     grl::TradeState tr;
     std::vector<void *> allocs;   // everything hipMalloc'ed by the handle
     std::vector<void *> user_allocs;
+    // per-kernel profiling (grl_profile_*)
+    bool prof_on;
+    std::vector<hipEvent_t> prof_ev;   // pairs
+    size_t prof_used;
 };
 
 namespace grl {
 int fail(grl_handle *h, int code, const std::string &msg);
+// bracket the dominant kernel of a step with an event pair when profiling is on
+void prof_begin(grl_handle *h);
+void prof_end(grl_handle *h);
 int hip_fail(grl_handle *h, hipError_t e, const char *what);
 #define GRL_HIP(h, call)                                        \
     do {                                                        \

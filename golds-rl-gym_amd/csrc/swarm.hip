@@ -446,10 +446,12 @@ int swarm_launch_step(grl_handle *h, const float *actions_dev) {
     SwarmParams P = make_params(h);
     P.actions = actions_dev;
     GRL_HIP(h, hipMemsetAsync(h->done_count, 0, sizeof(int32_t), h->stream));
+    prof_begin(h);
     if (h->cfg.flags & GRL_F_SWARM_FAST_MATH)
         hipLaunchKernelGGL((swarm_kernel<MODE_STEP, true>), dim3(nblocks(h->E)), dim3(SWARM_TPB), 0, h->stream, P);
     else
         hipLaunchKernelGGL((swarm_kernel<MODE_STEP, false>), dim3(nblocks(h->E)), dim3(SWARM_TPB), 0, h->stream, P);
+    prof_end(h);
     GRL_HIP(h, hipGetLastError());
     // auto-reset of the envs that just finished (paac/emulator_runner.py:128-132): the terminal
     // reward/done stay, the observation becomes the reset one (quirk Q6)

@@ -72,7 +72,10 @@ SIGNATURES = {
     "grl_dev_free": (C.c_int, [_P, _P]),
     "grl_dev_upload": (C.c_int, [_P, _P, _P, _SZ]),
     "grl_dev_download": (C.c_int, [_P, _P, _P, _SZ]),
+    "grl_dev_copy": (C.c_int, [_P, _P, _P, _SZ]),
     "grl_dev_randn": (C.c_int, [_P, _P, _SZ, C.c_uint32, C.c_uint64]),
+    "grl_profile_enable": (C.c_int, [_P, _I]),
+    "grl_profile_read": (C.c_int, [_P, C.POINTER(_I), C.POINTER(C.c_float)]),
     "grl_stream": (C.c_int, [_P, C.POINTER(_P)]),
     "grl_timer_start": (C.c_int, [_P]),
     "grl_timer_stop": (C.c_int, [_P]),
@@ -294,6 +297,25 @@ class Engine(object):
 
     def dev_randn(self, ptr, n, stream=0, counter=0):
         self._check(self.lib.grl_dev_randn(self.h, C.c_void_p(ptr), n, stream, counter))
+
+    def dev_copy(self, dst, src, nbytes):
+        self._check(self.lib.grl_dev_copy(self.h, C.c_void_p(dst), C.c_void_p(src), nbytes))
+
+    def transform_actions_device(self, ptr, rows):
+        self._check(self.lib.grl_transform_actions_device(self.h, C.c_void_p(ptr), rows))
+
+    def returns_device(self, r, v, mask, boot, T, B, gamma, lam, scale, clip_lo, clip_hi, y, adv):
+        self._check(self.lib.grl_returns_device(self.h, C.c_void_p(r), C.c_void_p(v), C.c_void_p(mask) if mask else None,
+                                                C.c_void_p(boot), T, B, gamma, lam, scale, clip_lo, clip_hi,
+                                                C.c_void_p(y), C.c_void_p(adv)))
+
+    def profile_enable(self, on=True):
+        self._check(self.lib.grl_profile_enable(self.h, 1 if on else 0))
+
+    def profile_read(self):
+        n, ms = C.c_int32(), C.c_float()
+        self._check(self.lib.grl_profile_read(self.h, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
 
     def timer_start(self):
         self._check(self.lib.grl_timer_start(self.h))

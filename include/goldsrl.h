@@ -196,6 +196,7 @@ int grl_dev_alloc(grl_handle *h, size_t bytes, void **out_dev);
 int grl_dev_free(grl_handle *h, void *dev);
 int grl_dev_upload(grl_handle *h, void *dst_dev, const void *src_host, size_t bytes);
 int grl_dev_download(grl_handle *h, void *dst_host, const void *src_dev, size_t bytes);
+int grl_dev_copy(grl_handle *h, void *dst_dev, const void *src_dev, size_t bytes); /* D2D, enqueued on the stream */
 /* Fill n float32 with N(0,1) from the handle's generator (stream id `stream`, counter base). */
 int grl_dev_randn(grl_handle *h, float *dst_dev, size_t n, uint32_t stream, uint64_t counter);
 /* Raw HIP stream of the handle (hipStream_t as void*), so callers can order their own work. */
@@ -205,6 +206,12 @@ int grl_stream(grl_handle *h, void **out_stream);
 int grl_timer_start(grl_handle *h);
 int grl_timer_stop(grl_handle *h);
 int grl_timer_ms(grl_handle *h, float *ms_out);
+
+/* Per-kernel timing for the roofline line of bench.py: while enabled, every launch of the env
+ * step kernel is bracketed by a HIP event pair on the handle's stream (up to 4096 launches).
+ * grl_profile_read syncs and returns the number of bracketed launches and their summed duration. */
+int grl_profile_enable(grl_handle *h, int32_t on);
+int grl_profile_read(grl_handle *h, int32_t *launches_out, float *total_ms_out);
 
 #ifdef __cplusplus
 }
