@@ -1,0 +1,291 @@
+"""CPU ORACLE for the policy/value networks -- TEST INFRASTRUCTURE ONLY.
+
+PARITY UNPINNED: the reference builds these nets from tensorflow==1.4.1 layers
+(/root/reference/requirements.txt:33), which is neither under /root/reference nor installable
+here, and the reference's own tests pin only output SHAPES and overfit-to-zero behaviour
+(/root/reference/tests/estimators_tests.py:24-129).  This file restates, in float64 numpy, the
+graph that /root/reference/fed_gym/agents/paac/policy_v_network.py:5-66 (ConvSingleAgentPolicyNetwork)
+and :194-251 (FlatPolicyVNetwork, with a3c/estimators.py:5-28) describe, using the published
+TF-1.4 semantics of tf.layers.Conv2D/Dense (VALID padding, NHWC, kernel [kh,kw,cin,cout], glorot
+uniform, zero bias), tf.nn.rnn_cell.GRUCell, tf.distributions.Normal, tf.clip_by_global_norm and
+tf.train.AdamOptimizer (/root/reference/fed_gym/agents/paac/actor_learner.py:31-68).
+The HIP kernels are checked against THIS restatement with shared weights, and this restatement is
+checked against itself by finite differences (tests/test_oracle_nets.py).
+"""
+import numpy as np
+
+LOG_2PI = np.log(2.0 * np.pi)
+
+# (name, shape) in the order tf.trainable_variables() creates them (policy_v_network.py:14-59)
+CONV_PARAM_SHAPES = [
+    ("conv1_w", (8, 8, 3, 32)), ("conv1_b", (32,)),
+    ("conv2_w", (4, 4, 32, 64)), ("conv2_b", (64,)),
+    ("conv3_w", (3, 3, 64, 64)), ("conv3_b", (64,)),
+    ("dense1_w", (3136, 512)), ("dense1_b", (512,)),
+    ("dense2_w", (512, 256)), ("dense2_b", (256,)),
+    ("pol1_w", (256, 512)), ("pol1_b", (512,)),
+    ("mu_w", (512, 2)), ("mu_b", (2,)),
+    ("sigma_w", (512, 2)), ("sigma_b", (2,)),
+    ("v1_w", (256, 512)), ("v1_b", (512,)),
+    ("v2_w", (512, 256)), ("v2_b", (256,)),
+    ("v3_w", (256, 1)), ("v3_b", (1,)),
+]
+CONV_NUM_PARAMS = sum(int(np.prod(s)) for _, s in CONV_PARAM_SHAPES)   # 2 210 213
+
+
+def glorot_uniform(rng, shape):
+    """tf.glorot_uniform_initializer: U(-l, l), l = sqrt(6/(fan_in+fan_out)); for conv kernels
+    fan_in = kh*kw*cin, fan_out = kh*kw*cout."""
+    if len(shape) == 2:
+        fan_in, fan_out = shape
+    else:
+        rf = int(np.prod(shape[:-2]))
+        fan_in, fan_out = rf * shape[-2], rf * shape[-1]
+    lim = np.sqrt(6.0 / (fan_in + fan_out))
+    return rng.uniform(-lim, lim, size=shape)
+
+
+def conv_init(seed=3):
+    rng = np.random.RandomState(seed)
+    return {n: (glorot_uniform(rng, s) if n.endswith("_w") else np.zeros(s)) for n, s in CONV_PARAM_SHAPES}
+
+
+def flatten_params(p, shapes=CONV_PARAM_SHAPES):
+    return np.concatenate([np.asarray(p[n], dtype=np.float64).reshape(-1) for n, _ in shapes])
+
+
+def unflatten_params(flat, shapes=CONV_PARAM_SHAPES):
+    out, o = {}, 0
+    for n, s in shapes:
+        k = int(np.prod(s))
+        out[n] = np.asarray(flat[o:o + k]).reshape(s)
+        o += k
+    return out
+
+
+def _im2col(x, kh, kw, stride):
+    """x (N,H,W,C) -> (N,OH,OW,kh*kw*C) with the (ky,kx,c) ordering of a TF [kh,kw,cin,cout] kernel."""
+    N, H, W, C = x.shape
+    oh, ow = (H - kh) // stride + 1, (W - kw) // stride + 1
+    cols = np.empty((N, oh, ow, kh, kw, C), dtype=x.dtype)
+    for ky in range(kh):
+        for kx in range(kw):
+            cols[:, :, :, ky, kx, :] = x[:, ky:ky + stride * oh:stride, kx:kx + stride * ow:stride, :]
+    return cols.reshape(N, oh, ow, kh * kw * C)
+
+
+def _col2im(dcols, xshape, kh, kw, stride):
+    N, H, W, C = xshape
+    oh, ow = (H - kh) // stride + 1, (W - kw) // stride + 1
+    d = dcols.reshape(N, oh, ow, kh, kw, C)
+    dx = np.zeros(xshape, dtype=dcols.dtype)
+    for ky in range(kh):
+        for kx in range(kw):
+            dx[:, ky:ky + stride * oh:stride, kx:kx + stride * ow:stride, :] += d[:, :, :, ky, kx, :]
+    return dx
+
+
+def _conv(x, w, b, stride):
+    kh, kw, cin, cout = w.shape
+    cols = _im2col(x, kh, kw, stride)
+    return cols @ w.reshape(-1, cout) + b, cols
+
+
+def softplus(x):
+    return np.logaddexp(0.0, x)
+
+
+def _sigmoid(x):
+    return 0.5 * (1.0 + np.tanh(0.5 * x))
+
+
+def conv_forward(p, states, scale, keep=False):
+    """ConvSingleAgentPolicyNetwork forward (policy_v_network.py:14-59).
+    states (N,84,84,3).  Returns mu (N,2), sigma (N,2), vs (N,) [+ cache]."""
+    c = {}
+    z1, c["cols1"] = _conv(states, p["conv1_w"], p["conv1_b"], 4); a1 = np.maximum(z1, 0)
+    z2, c["cols2"] = _conv(a1, p["conv2_w"], p["conv2_b"], 2); a2 = np.maximum(z2, 0)
+    z3, c["cols3"] = _conv(a2, p["conv3_w"], p["conv3_b"], 1); a3 = np.maximum(z3, 0)
+    flat = a3.reshape(a3.shape[0], -1)                       # tf.layers.flatten of NHWC: (h, w, c)
+    d1 = np.maximum(flat @ p["dense1_w"] + p["dense1_b"], 0)
+    d2 = np.maximum(d1 @ p["dense2_w"] + p["dense2_b"], 0)   # processed_state
+    p1 = np.maximum(d2 @ p["pol1_w"] + p["pol1_b"], 0)
+    mu = np.tanh(p1 @ p["mu_w"] + p["mu_b"])
+    sigma = _sigmoid(p1 @ p["sigma_w"] + p["sigma_b"])
+    v1 = np.maximum(d2 @ p["v1_w"] + p["v1_b"], 0)
+    v2 = np.maximum(v1 @ p["v2_w"] + p["v2_b"], 0)
+    zv = (v2 @ p["v3_w"] + p["v3_b"])[:, 0]
+    vs = -scale * softplus(zv)                               # policy_v_network.py:59
+    if keep:
+        c.update(a1=a1, a2=a2, a3=a3, flat=flat, d1=d1, d2=d2, p1=p1, mu=mu, sigma=sigma, v1=v1, v2=v2, zv=zv, vs=vs,
+                 states_shape=states.shape)
+        return mu, sigma, vs, c
+    return mu, sigma, vs
+
+
+def gaussian_loss_terms(mu, sigma, actions, advantages, critic_target, vs, beta, scale, entropy_in_loss=True):
+    """Loss of policy_v_network.py:45-66 (and :228-251 with entropy_in_loss=False, per-element nll).
+    Returns loss, policy_loss, critic_loss_mean, and d(loss)/d(mu, sigma, vs)."""
+    N, A = mu.shape
+    diff = actions - mu
+    logp = -0.5 * (diff / sigma) ** 2 - np.log(sigma) - 0.5 * LOG_2PI      # Normal.log_prob
+    ent = 0.5 + 0.5 * LOG_2PI + np.log(sigma)                                # Normal.entropy
+    if entropy_in_loss:
+        # -mean_n( sum_a logp * adv + beta * sum_a ent )
+        policy_loss = -np.mean(logp.sum(axis=1) * advantages + beta * ent.sum(axis=1))
+        dlogp = -(advantages / N)[:, None] * np.ones_like(mu)
+        dent = -(beta / N) * np.ones_like(mu)
+    else:
+        # mean over (n, a) of (-logp * adv[:, None]); no entropy term in the loss (:230-235)
+        policy_loss = np.mean(-logp * advantages[:, None])
+        dlogp = -(advantages / (N * A))[:, None] * np.ones_like(mu)
+        dent = np.zeros_like(mu)
+    dmu = dlogp * (diff / sigma ** 2)
+    dsigma = dlogp * ((diff ** 2) / sigma ** 3 - 1.0 / sigma) + dent / sigma
+    critic_loss = (vs - critic_target) ** 2 / scale
+    critic_loss_mean = np.mean(0.25 * critic_loss)
+    dvs = 0.5 * (vs - critic_target) / (scale * N)
+    return policy_loss + critic_loss_mean, policy_loss, critic_loss_mean, dmu, dsigma, dvs
+
+
+def conv_loss_and_grads(p, states, actions, advantages, critic_target, beta, scale):
+    """loss and d loss / d params for N1 (float64)."""
+    mu, sigma, vs, c = conv_forward(p, states, scale, keep=True)
+    loss, pl, cl, dmu, dsigma, dvs = gaussian_loss_terms(mu, sigma, actions, advantages, critic_target, vs, beta, scale)
+    g = {}
+    dzmu = dmu * (1 - mu ** 2)
+    dzsig = dsigma * sigma * (1 - sigma)
+    g["mu_w"], g["mu_b"] = c["p1"].T @ dzmu, dzmu.sum(0)
+    g["sigma_w"], g["sigma_b"] = c["p1"].T @ dzsig, dzsig.sum(0)
+    dp1 = (dzmu @ p["mu_w"].T + dzsig @ p["sigma_w"].T) * (c["p1"] > 0)
+    g["pol1_w"], g["pol1_b"] = c["d2"].T @ dp1, dp1.sum(0)
+    dzv = (dvs * (-scale) * _sigmoid(c["zv"]))[:, None]
+    g["v3_w"], g["v3_b"] = c["v2"].T @ dzv, dzv.sum(0)
+    dv2 = (dzv @ p["v3_w"].T) * (c["v2"] > 0)
+    g["v2_w"], g["v2_b"] = c["v1"].T @ dv2, dv2.sum(0)
+    dv1 = (dv2 @ p["v2_w"].T) * (c["v1"] > 0)
+    g["v1_w"], g["v1_b"] = c["d2"].T @ dv1, dv1.sum(0)
+    dd2 = (dp1 @ p["pol1_w"].T + dv1 @ p["v1_w"].T) * (c["d2"] > 0)
+    g["dense2_w"], g["dense2_b"] = c["d1"].T @ dd2, dd2.sum(0)
+    dd1 = (dd2 @ p["dense2_w"].T) * (c["d1"] > 0)
+    g["dense1_w"], g["dense1_b"] = c["flat"].T @ dd1, dd1.sum(0)
+    da3 = (dd1 @ p["dense1_w"].T).reshape(c["a3"].shape) * (c["a3"] > 0)
+    g["conv3_w"] = (c["cols3"].reshape(-1, c["cols3"].shape[-1]).T @ da3.reshape(-1, 64)).reshape(p["conv3_w"].shape)
+    g["conv3_b"] = da3.sum(axis=(0, 1, 2))
+    da2 = _col2im(da3 @ p["conv3_w"].reshape(-1, 64).T, c["a2"].shape, 3, 3, 1) * (c["a2"] > 0)
+    g["conv2_w"] = (c["cols2"].reshape(-1, c["cols2"].shape[-1]).T @ da2.reshape(-1, 64)).reshape(p["conv2_w"].shape)
+    g["conv2_b"] = da2.sum(axis=(0, 1, 2))
+    da1 = _col2im(da2 @ p["conv2_w"].reshape(-1, 64).T, c["a1"].shape, 4, 4, 2) * (c["a1"] > 0)
+    g["conv1_w"] = (c["cols1"].reshape(-1, c["cols1"].shape[-1]).T @ da1.reshape(-1, 32)).reshape(p["conv1_w"].shape)
+    g["conv1_b"] = da1.sum(axis=(0, 1, 2))
+    return loss, pl, cl, g, (mu, sigma, vs)
+
+
+def clip_by_global_norm(grads_flat, clip_norm):
+    """tf.clip_by_global_norm (actor_learner.py:52-57): g * clip / max(norm, clip)."""
+    norm = np.sqrt(np.sum(grads_flat ** 2))
+    return grads_flat * (clip_norm / max(norm, clip_norm)), norm
+
+
+def adam_step(params_flat, grads_flat, m, v, t, lr, b1=0.9, b2=0.999, eps=1e-8):
+    """tf.train.AdamOptimizer (TF 1.4): lr_t = lr*sqrt(1-b2^t)/(1-b1^t);
+    m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr_t * m / (sqrt(v) + eps).  t starts at 1."""
+    lr_t = lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t)
+    m = b1 * m + (1 - b1) * grads_flat
+    v = b2 * v + (1 - b2) * grads_flat ** 2
+    return params_flat - lr_t * m / (np.sqrt(v) + eps), m, v
+
+
+# ------------------------------------------------------------------------------------------ Flat net
+def flat_param_shapes(static_size=2, temporal_size=2, static_hidden=32, rnn_hidden=32, num_actions=1):
+    """FlatPolicyVNetwork variables (policy_v_network.py:207-244, a3c/estimators.py:18-28)."""
+    H, S = rnn_hidden, static_hidden
+    return [
+        ("gru_gates_w", (temporal_size + H, 2 * H)), ("gru_gates_b", (2 * H,)),     # r,u gates; bias init 1.0
+        ("gru_cand_w", (temporal_size + H, H)), ("gru_cand_b", (H,)),
+        ("temporal_w", (H, 2 * H)), ("temporal_b", (2 * H,)),
+        ("static1_w", (static_size, 2 * H)), ("static1_b", (2 * H,)),
+        ("static2_w", (2 * H, H)), ("static2_b", (H,)),
+        ("mu1_w", (3 * H, 2 * S)), ("mu1_b", (2 * S,)),
+        ("mu2_w", (2 * S, S)), ("mu2_b", (S,)),
+        ("mu3_w", (S, num_actions)), ("mu3_b", (num_actions,)),
+        ("sig1_w", (3 * H, 2 * S)), ("sig1_b", (2 * S,)),
+        ("sig2_w", (2 * S, S)), ("sig2_b", (S,)),
+        ("sig3_w", (S, num_actions)), ("sig3_b", (num_actions,)),                   # bias init -1.0
+        ("v1_w", (3 * H, 2 * S)), ("v1_b", (2 * S,)),
+        ("v2_w", (2 * S, 1)), ("v2_b", (1,)),
+    ]
+
+
+def flat_init(seed=3, **kw):
+    rng = np.random.RandomState(seed)
+    p = {}
+    for n, s in flat_param_shapes(**kw):
+        if n.endswith("_w"):
+            p[n] = glorot_uniform(rng, s)
+        elif n == "gru_gates_b":
+            p[n] = np.ones(s)        # GRUCell gate bias initialiser = 1.0
+        elif n == "sig3_b":
+            p[n] = -np.ones(s)       # policy_v_network.py:225
+        else:
+            p[n] = np.zeros(s)
+    return p
+
+
+def gru_last_state(p, history):
+    """tf.nn.dynamic_rnn(GRUCell) with sequence_length = #rows whose max|x| > 0
+    (a3c/estimators.py:11-23): state stops updating once t >= length.  history (N,T,D)."""
+    N, T, D = history.shape
+    H = p["gru_cand_b"].shape[0]
+    length = np.sign(np.max(np.abs(history), axis=2)).sum(axis=1).astype(int)
+    h = np.zeros((N, H))
+    for t in range(T):
+        x = history[:, t]
+        gates = _sigmoid(np.concatenate([x, h], 1) @ p["gru_gates_w"] + p["gru_gates_b"])
+        r, u = gates[:, :H], gates[:, H:]
+        c = np.tanh(np.concatenate([x, r * h], 1) @ p["gru_cand_w"] + p["gru_cand_b"])
+        h_new = u * h + (1 - u) * c
+        h = np.where((t < length)[:, None], h_new, h)
+    return h
+
+
+def flat_forward(p, states, history, scale, ub=5.0, lb=-5.0):
+    """FlatPolicyVNetwork forward (policy_v_network.py:207-244)."""
+    h = gru_last_state(p, history)
+    dense_temporal = np.maximum(h @ p["temporal_w"] + p["temporal_b"], 0)
+    s1 = np.maximum(states @ p["static1_w"] + p["static1_b"], 0)
+    s2 = np.maximum(s1 @ p["static2_w"] + p["static2_b"], 0)
+    x = np.concatenate([dense_temporal, s2], axis=1)
+    m = np.maximum(x @ p["mu1_w"] + p["mu1_b"], 0)
+    m = np.tanh(m @ p["mu2_w"] + p["mu2_b"])
+    mu = ((ub - lb) / 2.0) * np.tanh(m @ p["mu3_w"] + p["mu3_b"]) + (lb + ub) / 2.0
+    s = np.maximum(x @ p["sig1_w"] + p["sig1_b"], 0)
+    s = np.tanh(s @ p["sig2_w"] + p["sig2_b"])
+    sigma = _sigmoid(s @ p["sig3_w"] + p["sig3_b"]) + 1e-3
+    v = np.tanh(x @ p["v1_w"] + p["v1_b"])
+    vs = scale * (v @ p["v2_w"] + p["v2_b"])[:, 0]
+    return mu, sigma, vs
+
+
+def flat_loss(p, states, history, actions, advantages, critic_target, scale):
+    mu, sigma, vs = flat_forward(p, states, history, scale)
+    loss, pl, cl, _, _, _ = gaussian_loss_terms(mu, sigma, actions, advantages, critic_target, vs, 0.0, scale,
+                                                entropy_in_loss=False)
+    return loss, pl, cl
+
+
+def numeric_grad(f, p, names, eps=1e-6, max_per=6, seed=0):
+    """Central finite differences on a few random entries of each named parameter."""
+    rng = np.random.RandomState(seed)
+    out = {}
+    for n in names:
+        idxs = [tuple(rng.randint(0, s) for s in p[n].shape) for _ in range(max_per)]
+        vals = []
+        for idx in idxs:
+            old = p[n][idx]
+            p[n][idx] = old + eps; fp = f(p)
+            p[n][idx] = old - eps; fm = f(p)
+            p[n][idx] = old
+            vals.append((idx, (fp - fm) / (2 * eps)))
+        out[n] = vals
+    return out

@@ -1,0 +1,73 @@
+"""The network oracle (oracle/nets.py) is 'parity unpinned' (no TF here): check it against itself --
+analytic gradients vs central finite differences, parameter count vs SURVEY N1, GRU masking."""
+import numpy as np
+
+from oracle import nets as NN
+
+
+def _tiny_batch(n=3, seed=0):
+    rng = np.random.RandomState(seed)
+    states = np.zeros((n, 84, 84, 3))
+    for i in range(n):
+        for _ in range(80):
+            states[i, rng.randint(84), rng.randint(84), 0] += 1 / 80.0
+        for _ in range(10):
+            states[i, rng.randint(84), rng.randint(84), 1] += 1 / 10.0
+        states[i, rng.randint(84), rng.randint(84), 2] = 1.0
+    return states, rng.normal(size=(n, 2)), rng.normal(size=n) * 0.01, -rng.rand(n) * 300
+
+
+def test_param_count_matches_survey():
+    assert NN.CONV_NUM_PARAMS == 2210213
+    p = NN.conv_init()
+    flat = NN.flatten_params(p)
+    assert flat.size == 2210213
+    q = NN.unflatten_params(flat)
+    assert all(np.array_equal(p[k], q[k]) for k in p)
+    n_flat = sum(int(np.prod(s)) for _, s in NN.flat_param_shapes())
+    assert 30000 < n_flat < 32000          # "~30.7k params" 
+
+
+def test_conv_shapes_and_ranges():
+    p = NN.conv_init()
+    s, a, adv, y = _tiny_batch()
+    mu, sigma, vs = NN.conv_forward(p, s, 1000.0)
+    assert mu.shape == (3, 2) and sigma.shape == (3, 2) and vs.shape == (3,)     # estimators_tests.py:72-76
+    assert (np.abs(mu) <= 1).all() and (sigma > 0).all() and (sigma < 1).all() and (vs < 0).all()
+
+
+def test_conv_gradients_match_finite_differences():
+    p = NN.conv_init(seed=5)
+    for k in p:                      # move biases off zero so ReLU gates are generic
+        if k.endswith("_b"):
+            p[k] = np.random.RandomState(1).normal(size=p[k].shape) * 0.05
+    s, a, adv, y = _tiny_batch()
+    beta, scale = 0.02, 1000.0
+    loss, pl, cl, g, _ = NN.conv_loss_and_grads(p, s, a, adv, y, beta, scale)
+    f = lambda q: NN.conv_loss_and_grads(q, s, a, adv, y, beta, scale)[0]
+    num = NN.numeric_grad(f, p, [n for n, _ in NN.CONV_PARAM_SHAPES], eps=1e-6, max_per=3)
+    for n, vals in num.items():
+        for idx, gv in vals:
+            assert abs(g[n][idx] - gv) <= 2e-4 * abs(gv) + 2e-6, (n, idx, g[n][idx], gv)
+
+
+def test_clip_and_adam():
+    g = np.array([3.0, 4.0])
+    c, n = NN.clip_by_global_norm(g, 1.0)
+    assert n == 5.0 and np.allclose(c, g / 5.0)
+    c, n = NN.clip_by_global_norm(g, 40.0)
+    assert np.array_equal(c, g)
+    p, m, v = NN.adam_step(np.zeros(2), g, np.zeros(2), np.zeros(2), 1, 1e-3)
+    assert np.allclose(p, -1e-3 * np.sign(g), rtol=1e-6)      # first Adam step is lr*sign(g)
+
+
+def test_gru_sequence_length_masking():
+    p = NN.flat_init()
+    rng = np.random.RandomState(0)
+    hist = rng.normal(size=(4, 5, 2))
+    hist[1, 2:] = 0; hist[2, 1:] = 0
+    h = NN.gru_last_state(p, hist)
+    h_short = NN.gru_last_state(p, hist[1:2, :2])
+    assert np.allclose(h[1], h_short[0])
+    mu, sigma, vs = NN.flat_forward(p, rng.normal(size=(4, 2)), hist, 100.0)
+    assert (np.abs(mu) <= 5).all() and (sigma > 1e-3).all() and mu.shape == (4, 1)
