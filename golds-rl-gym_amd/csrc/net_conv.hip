@@ -1,0 +1,465 @@
+// ConvSingleAgentPolicyNetwork on gfx950 (reference fed_gym/agents/paac/policy_v_network.py:5-80):
+// forward, Gaussian action sampling (paac/paac.py:414-419), loss + backward, clip-by-global-norm and
+// Adam (paac/actor_learner.py:31-68), and the device-resident PAAC rollout (paac/paac.py:302-372).
+//
+// The 84x84x3 input image is never materialised: conv1 (8x8/4) is evaluated SPARSELY from the
+// compact observation -- an image has at most 80+10+1 non-zero pixels, so the exact same sum has
+// ~12k instead of 2.46M multiply-adds -- by one workgroup per env that stages the 84x84 count
+// grids in LDS, builds the pre-activation shared by the env's 10 agents once, and adds each
+// agent's one-hot tap.  conv2/conv3/dense layers are fp32-MFMA implicit GEMMs (net_gemm.h).
+#include <string.h>
+
+#include <cmath>
+#include <string>
+#include <vector>
+
+#include "../../include/goldsrl_net.h"
+#include "common.h"
+#include "net_gemm.h"
+#include "rng.h"
+
+namespace grl {
+
+enum : uint32_t { RS_ACTION = 16 };
+
+// parameter offsets in the flat vector (tf.trainable_variables() order)
+struct ConvOffsets {
+    static constexpr long c1w = 0, c1b = c1w + 8 * 8 * 3 * 32, c2w = c1b + 32, c2b = c2w + 4 * 4 * 32 * 64, c3w = c2b + 64,
+                          c3b = c3w + 3 * 3 * 64 * 64, d1w = c3b + 64, d1b = d1w + 3136 * 512, d2w = d1b + 512,
+                          d2b = d2w + 512 * 256, p1w = d2b + 256, p1b = p1w + 256 * 512, muw = p1b + 512, mub = muw + 1024,
+                          sgw = mub + 2, sgb = sgw + 1024, v1w = sgb + 2, v1b = v1w + 256 * 512, v2w = v1b + 512,
+                          v2b = v2w + 512 * 256, v3w = v2b + 256, v3b = v3w + 256, total = v3b + 1;
+};
+static_assert(ConvOffsets::total == 2210213, "parameter count (SURVEY N1)");
+
+using GatherConv2 = ConvGather<9, 9, 2, 2, 0, 0, 4, 4, 32, 20, 20, false>;    // a1[n][20][20][32] -> (n*81, 512)
+using GatherConv3 = ConvGather<7, 7, 1, 1, 0, 0, 3, 3, 64, 9, 9, false>;      // a2[n][9][9][64]  -> (n*49, 576)
+// data gradients (transposed convolutions, zero-filled borders):
+using GatherT3 = ConvGather<9, 9, 1, 1, -2, -2, 3, 3, 64, 7, 7, true>;        // dz3[n][7][7][64] -> rows (n,y,x) of a2
+using GatherT2 = ConvGather<10, 10, 1, 1, -1, -1, 2, 2, 64, 9, 9, true>;      // dz2[n][9][9][64] -> rows (n,yh,xh) per parity
+
+}  // namespace grl
+
+struct grl_net {
+    grl_handle *h;
+    grl_net_config cfg;
+    std::string err;
+    int chunk;                 // samples per pass
+    float *params, *grads, *adam_m, *adam_v;
+    long adam_t;
+    // forward activations (chunk)
+    float *a1, *a2, *a3, *d1, *d2, *p1, *v1, *v2;
+    // gradients of activations (chunk)
+    float *ga1, *ga2, *ga3, *gd1, *gd2, *gp1, *gv1, *gv2;
+    float *w3t, *w2t;          // rearranged conv weights for the data gradients
+    float *slab;               // split-M partial sums
+    size_t slab_floats;
+    double *slab64;
+    float *stats;              // device: loss sums
+    // rollout storage (allocated by grl_net_rollout)
+    int T, B;
+    uint8_t *ro_lb, *ro_ab, *ro_pos;
+    float *ro_act, *ro_envact, *ro_val, *ro_rew, *ro_y, *ro_adv, *ro_boot, *ro_mu, *ro_sigma;
+    float *mu, *sigma, *vs;    // (B,2) (B,2) (B) of the last predict
+    uint8_t *tmp_lb, *tmp_ab, *tmp_pos;
+    int tmp_envs;
+    unsigned long act_counter;
+    std::vector<void *> allocs;
+    bool prof_on;
+    std::vector<hipEvent_t> prof_ev;
+    size_t prof_used;
+    double prof_flops;
+    int last_n;                // samples in the last chunk (for read_activation)
+};
+
+namespace grl {
+
+static int nfail(grl_net *n, int code, const std::string &msg) {
+    if (n) n->err = msg;
+    return code;
+}
+#define NET_HIP(n, call)                                                                                   \
+    do {                                                                                                   \
+        hipError_t _e = (call);                                                                            \
+        if (_e != hipSuccess) return nfail(n, GRL_E_HIP, std::string(#call) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+template <typename T>
+static int nalloc(grl_net *n, T **p, size_t count) {
+    NET_HIP(n, hipMalloc((void **)p, count * sizeof(T)));
+    n->allocs.push_back(*p);
+    NET_HIP(n, hipMemsetAsync(*p, 0, count * sizeof(T), n->h->stream));
+    return GRL_OK;
+}
+
+struct GemmTimer {
+    grl_net *n;
+    GemmTimer(grl_net *net, double flops) : n(net) {
+        if (n->prof_on && n->prof_used + 2 <= n->prof_ev.size()) {
+            (void)hipEventRecord(n->prof_ev[n->prof_used], n->h->stream);
+            n->prof_flops += flops;
+        }
+    }
+    ~GemmTimer() {
+        if (n->prof_on && n->prof_used + 2 <= n->prof_ev.size()) {
+            (void)hipEventRecord(n->prof_ev[n->prof_used + 1], n->h->stream);
+            n->prof_used += 2;
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------ conv1 (sparse)
+// One workgroup per env.  Axis convention of the reference image: states[n][h][w][c] with h = x-bin,
+// w = y-bin (np.histogram2d's first output axis is x; state_processors.py:31-33).
+__global__ __launch_bounds__(256) void conv1_sparse_kernel(const uint8_t *__restrict__ lbins, const uint8_t *__restrict__ abins,
+                                                           const uint8_t *__restrict__ pos, const float *__restrict__ w1,
+                                                           const float *__restrict__ b1, float *__restrict__ a1, int G) {
+    __shared__ unsigned int cnt[2][7056 / 4 + 4];   // 84x84 byte counters per channel, packed 4 per word
+    __shared__ float S[400 * 32];                    // pre-activation shared by the env's 10 agents
+    const int env = blockIdx.x, tid = threadIdx.x;
+    for (int i = tid; i < 2 * (7056 / 4 + 4); i += 256) (&cnt[0][0])[i] = 0;
+    __syncthreads();
+    if (tid < 80) {
+        int bx = lbins[((size_t)env * 80 + tid) * 2], by = lbins[((size_t)env * 80 + tid) * 2 + 1];
+        if (bx != 255) { int idx = bx * G + by; atomicAdd(&cnt[0][idx >> 2], 1u << (8 * (idx & 3))); }
+    } else if (tid < 90) {
+        int a = tid - 80;
+        int bx = abins[((size_t)env * 10 + a) * 2], by = abins[((size_t)env * 10 + a) * 2 + 1];
+        if (bx != 255) { int idx = bx * G + by; atomicAdd(&cnt[1][idx >> 2], 1u << (8 * (idx & 3))); }
+    }
+    __syncthreads();
+    for (int pix = tid; pix < 400; pix += 256) {
+        const int oy = pix / 20, ox = pix - oy * 20;
+        float acc[32];
+#pragma unroll
+        for (int co = 0; co < 32; ++co) acc[co] = b1[co];
+        for (int ky = 0; ky < 8; ++ky) {
+            const int rowbase = (4 * oy + ky) * G + 4 * ox;   // multiple of 4: G = 84
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                unsigned int w0 = cnt[c][rowbase >> 2], w1_ = cnt[c][(rowbase >> 2) + 1];
+                if ((w0 | w1_) == 0) continue;
+#pragma unroll
+                for (int kx = 0; kx < 8; ++kx) {
+                    unsigned int k = ((kx < 4 ? w0 : w1_) >> (8 * (kx & 3))) & 255u;
+                    if (k == 0) continue;
+                    // x_grid / len(state[0]) in float64, fed to the float32 placeholder (state_processors.py:33)
+                    float val = (float)((double)k / (c == 0 ? 80.0 : 10.0));
+                    const float *wp = w1 + ((ky * 8 + kx) * 3 + c) * 32;
+#pragma unroll
+                    for (int co = 0; co < 32; ++co) acc[co] += val * wp[co];
+                }
+            }
+        }
+#pragma unroll
+        for (int co = 0; co < 32; ++co) S[pix * 32 + co] = acc[co];
+    }
+    __syncthreads();
+    for (int a = 0; a < 10; ++a) {
+        const int ph = pos[((size_t)env * 10 + a) * 2], pw = pos[((size_t)env * 10 + a) * 2 + 1];
+        float4 *out = reinterpret_cast<float4 *>(a1 + ((size_t)env * 10 + a) * 12800);
+        for (int i = tid; i < 3200; i += 256) {
+            const int pix = i >> 3, co = (i & 7) * 4;
+            const int oy = pix / 20, ox = pix - oy * 20;
+            float4 v = *reinterpret_cast<const float4 *>(&S[pix * 32 + co]);
+            const int ky = ph - 4 * oy, kx = pw - 4 * ox;
+            if ((unsigned)ky < 8u && (unsigned)kx < 8u) {   // the agent's one-hot pixel lies in this window
+                const float *wp = w1 + ((ky * 8 + kx) * 3 + 2) * 32 + co;
+                v.x += wp[0]; v.y += wp[1]; v.z += wp[2]; v.w += wp[3];
+            }
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            out[i] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ heads
+// mu = tanh(p1 Wmu + b), sigma = sigmoid(p1 Wsg + b), vs = -scale*softplus(v2 Wv3 + b)
+// (policy_v_network.py:40-59).  One wave per sample row.
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void heads_forward_kernel(const float *__restrict__ p1, const float *__restrict__ v2,
+                                                            const float *__restrict__ params, int n, float scale,
+                                                            float *__restrict__ mu, float *__restrict__ sigma, float *__restrict__ vs) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= n) return;
+    const float *muw = params + ConvOffsets::muw, *sgw = params + ConvOffsets::sgw, *v3w = params + ConvOffsets::v3w;
+    float m0 = 0, m1 = 0, s0 = 0, s1 = 0, zv = 0;
+    for (int k = lane; k < 512; k += 64) {
+        float x = p1[(size_t)row * 512 + k];
+        m0 += x * muw[k * 2]; m1 += x * muw[k * 2 + 1];
+        s0 += x * sgw[k * 2]; s1 += x * sgw[k * 2 + 1];
+    }
+    for (int k = lane; k < 256; k += 64) zv += v2[(size_t)row * 256 + k] * v3w[k];
+    m0 = wave_sum(m0); m1 = wave_sum(m1); s0 = wave_sum(s0); s1 = wave_sum(s1); zv = wave_sum(zv);
+    if (lane == 0) {
+        m0 += params[ConvOffsets::mub]; m1 += params[ConvOffsets::mub + 1];
+        s0 += params[ConvOffsets::sgb]; s1 += params[ConvOffsets::sgb + 1];
+        zv += params[ConvOffsets::v3b];
+        mu[(size_t)row * 2] = tanhf(m0); mu[(size_t)row * 2 + 1] = tanhf(m1);
+        sigma[(size_t)row * 2] = 1.0f / (1.0f + expf(-s0)); sigma[(size_t)row * 2 + 1] = 1.0f / (1.0f + expf(-s1));
+        float sp = zv > 20.f ? zv : log1pf(expf(zv));
+        vs[row] = -scale * sp;
+    }
+}
+
+// a = mu + sigma * N(0,1) (paac.py:418), then SwarmRunner.transform_actions_for_env (emulator_runner.py:113-118)
+__global__ void sample_actions_kernel(const float *__restrict__ mu, const float *__restrict__ sigma, int n, uint64_t seed,
+                                      uint32_t env_off, uint32_t counter, float *__restrict__ raw, float *__restrict__ envact) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int env = i / 10, a = i - env * 10;
+    double e0, e1;
+    normal_pair(rng_block(seed, (uint32_t)env + env_off, counter, RS_ACTION, a), e0, e1);
+    float2 m = reinterpret_cast<const float2 *>(mu)[i], s = reinterpret_cast<const float2 *>(sigma)[i];
+    float2 r = make_float2((float)((double)m.x + (double)s.x * e0), (float)((double)m.y + (double)s.y * e1));
+    reinterpret_cast<float2 *>(raw)[i] = r;
+    float d = sqrtf(r.x * r.x + r.y * r.y);
+    if (d >= 1.0f) { r.x /= d; r.y /= d; }
+    reinterpret_cast<float2 *>(envact)[i] = r;
+}
+
+// ------------------------------------------------------------------------------------------ forward pass of one chunk
+static int forward_chunk(grl_net *net, const uint8_t *lb, const uint8_t *ab, const uint8_t *pos, int nenv, float *mu,
+                         float *sigma, float *vs) {
+    hipStream_t st = net->h->stream;
+    const float *P = net->params;
+    const int n = nenv * 10;
+    net->last_n = n;
+    hipLaunchKernelGGL(conv1_sparse_kernel, dim3(nenv), dim3(256), 0, st, lb, ab, pos, P + ConvOffsets::c1w, P + ConvOffsets::c1b,
+                       net->a1, net->h->cfg.grid_size);
+    {
+        GatherConv2 g{net->a1, n * 81};
+        EpiBiasAct e{net->a2, 64, P + ConvOffsets::c2b, ACT_RELU};
+        GemmTimer t(net, 2.0 * n * 81 * 512 * 64);
+        hipLaunchKernelGGL((gemm_rowk<256, 64, 4, 1, false, GatherConv2, EpiBiasAct>), dim3((n * 81 + 255) / 256, 1), dim3(256), 0, st,
+                           g, P + ConvOffsets::c2w, 64, 64, e);
+    }
+    {
+        GatherConv3 g{net->a2, n * 49};
+        EpiBiasAct e{net->a3, 64, P + ConvOffsets::c3b, ACT_RELU};
+        GemmTimer t(net, 2.0 * n * 49 * 576 * 64);
+        hipLaunchKernelGGL((gemm_rowk<256, 64, 4, 1, false, GatherConv3, EpiBiasAct>), dim3((n * 49 + 255) / 256, 1), dim3(256), 0, st,
+                           g, P + ConvOffsets::c3w, 64, 64, e);
+    }
+    auto dense = [&](const float *in, int K, const float *w, const float *b, int N, float *out) {
+        DenseRows g{in, n, K, K};
+        EpiBiasAct e{out, N, b, ACT_RELU};
+        GemmTimer t(net, 2.0 * n * K * N);
+        hipLaunchKernelGGL((gemm_rowk<128, 128, 2, 2, false, DenseRows, EpiBiasAct>), dim3((n + 127) / 128, N / 128), dim3(256), 0, st, g,
+                           w, N, N, e);
+    };
+    dense(net->a3, 3136, P + ConvOffsets::d1w, P + ConvOffsets::d1b, 512, net->d1);
+    dense(net->d1, 512, P + ConvOffsets::d2w, P + ConvOffsets::d2b, 256, net->d2);
+    dense(net->d2, 256, P + ConvOffsets::p1w, P + ConvOffsets::p1b, 512, net->p1);
+    dense(net->d2, 256, P + ConvOffsets::v1w, P + ConvOffsets::v1b, 512, net->v1);
+    dense(net->v1, 512, P + ConvOffsets::v2w, P + ConvOffsets::v2b, 256, net->v2);
+    hipLaunchKernelGGL(heads_forward_kernel, dim3((n + 3) / 4), dim3(256), 0, st, net->p1, net->v2, P, n, net->cfg.scale, mu, sigma, vs);
+    NET_HIP(net, hipGetLastError());
+    return GRL_OK;
+}
+
+// forward over n_envs envs in chunks; obs pointers are DEVICE pointers; outputs device (B,2)(B,2)(B)
+static int forward_all(grl_net *net, const uint8_t *lb, const uint8_t *ab, const uint8_t *pos, int n_envs, float *mu, float *sigma,
+                       float *vs) {
+    const int ce = net->chunk / 10;
+    for (int e0 = 0; e0 < n_envs; e0 += ce) {
+        int ne = n_envs - e0 < ce ? n_envs - e0 : ce;
+        int rc = forward_chunk(net, lb + (size_t)e0 * 160, ab + (size_t)e0 * 20, pos + (size_t)e0 * 20, ne, mu + (size_t)e0 * 20,
+                               sigma + (size_t)e0 * 20, vs + (size_t)e0 * 10);
+        if (rc) return rc;
+    }
+    return GRL_OK;
+}
+
+static int ensure_tmp_obs(grl_net *net, int n_envs) {
+    if (net->tmp_envs >= n_envs) return GRL_OK;
+    int rc;
+    if ((rc = nalloc(net, &net->tmp_lb, (size_t)n_envs * 160))) return rc;
+    if ((rc = nalloc(net, &net->tmp_ab, (size_t)n_envs * 20))) return rc;
+    if ((rc = nalloc(net, &net->tmp_pos, (size_t)n_envs * 20))) return rc;
+    float *m, *s, *v;
+    if ((rc = nalloc(net, &m, (size_t)n_envs * 20))) return rc;
+    if ((rc = nalloc(net, &s, (size_t)n_envs * 20))) return rc;
+    if ((rc = nalloc(net, &v, (size_t)n_envs * 10))) return rc;
+    net->mu = m; net->sigma = s; net->vs = v;
+    net->tmp_envs = n_envs;
+    return GRL_OK;
+}
+
+}  // namespace grl
+
+using namespace grl;
+
+extern "C" {
+
+int grl_net_config_default(int32_t kind, grl_net_config *cfg) {
+    if (!cfg || kind != GRL_NET_CONV_SINGLE_AGENT) return GRL_E_INVALID;
+    memset(cfg, 0, sizeof(*cfg));
+    cfg->struct_size = (int32_t)sizeof(grl_net_config);
+    cfg->kind = kind;
+    cfg->max_chunk_samples = 40960;
+    cfg->scale = 1000.f;          // train_paac_conv.py:113
+    cfg->entropy_beta = 0.02f;    // :103
+    cfg->clip_norm = 40.f;        // :104
+    cfg->gamma = 0.99f;           // :106
+    return GRL_OK;
+}
+
+int grl_net_create(grl_handle *h, const grl_net_config *cfg, grl_net **out) {
+    if (!h || !cfg || !out) return GRL_E_INVALID;
+    *out = nullptr;
+    if (cfg->struct_size != (int32_t)sizeof(grl_net_config)) return fail(h, GRL_E_INVALID, "grl_net_create: grl_net_config size mismatch");
+    if (cfg->kind != GRL_NET_CONV_SINGLE_AGENT) return fail(h, GRL_E_INVALID, "grl_net_create: unknown kind");
+    if (h->cfg.env_kind != GRL_ENV_SWARM || h->cfg.grid_size != 84)
+        return fail(h, GRL_E_INVALID, "grl_net_create: the conv net needs a Swarm handle with grid_size 84 (84x84x3 input)");
+    if (cfg->max_chunk_samples < 10 || cfg->max_chunk_samples % 10 || cfg->max_chunk_samples > 131072)
+        return fail(h, GRL_E_INVALID, "grl_net_create: max_chunk_samples must be a multiple of 10 in 10..131072");
+    hipSetDevice(h->cfg.device_id);
+    grl_net *n = new grl_net();
+    n->h = h; n->cfg = *cfg; n->chunk = cfg->max_chunk_samples; n->adam_t = 0;
+    n->T = 0; n->B = 0; n->tmp_envs = 0; n->act_counter = 0; n->prof_on = false; n->prof_used = 0; n->prof_flops = 0; n->last_n = 0;
+    n->ro_lb = nullptr; n->slab = nullptr; n->slab_floats = 0; n->slab64 = nullptr; n->w3t = n->w2t = nullptr;
+    n->ga1 = nullptr; n->mu = n->sigma = n->vs = nullptr;
+    size_t c = n->chunk;
+    int rc = GRL_OK;
+    auto A = [&](float **p, size_t cnt) { if (rc == GRL_OK) rc = nalloc(n, p, cnt); };
+    A(&n->params, ConvOffsets::total); A(&n->grads, ConvOffsets::total); A(&n->adam_m, ConvOffsets::total); A(&n->adam_v, ConvOffsets::total);
+    A(&n->a1, c * 12800); A(&n->a2, c * 5184); A(&n->a3, c * 3136); A(&n->d1, c * 512); A(&n->d2, c * 256);
+    A(&n->p1, c * 512); A(&n->v1, c * 512); A(&n->v2, c * 256); A(&n->stats, 16);
+    if (rc == GRL_OK) rc = ensure_tmp_obs(n, h->E);
+    if (rc != GRL_OK) {
+        fail(h, rc, "grl_net_create: " + n->err);
+        grl_net_destroy(n);
+        return rc;
+    }
+    hipStreamSynchronize(h->stream);
+    *out = n;
+    return GRL_OK;
+}
+
+int grl_net_destroy(grl_net *n) {
+    if (!n) return GRL_OK;
+    hipSetDevice(n->h->cfg.device_id);
+    hipStreamSynchronize(n->h->stream);
+    for (void *p : n->allocs) hipFree(p);
+    for (hipEvent_t ev : n->prof_ev) hipEventDestroy(ev);
+    delete n;
+    return GRL_OK;
+}
+
+const char *grl_net_last_error(const grl_net *n) { return n ? n->err.c_str() : ""; }
+int64_t grl_net_num_params(const grl_net *n) { return n ? ConvOffsets::total : 0; }
+
+int grl_net_set_params(grl_net *n, const float *host, int64_t cnt) {
+    if (!n || !host) return GRL_E_INVALID;
+    if (cnt != ConvOffsets::total) return nfail(n, GRL_E_SIZE, "grl_net_set_params: expected " + std::to_string((long)ConvOffsets::total) + " floats");
+    hipSetDevice(n->h->cfg.device_id);
+    NET_HIP(n, hipStreamSynchronize(n->h->stream));
+    NET_HIP(n, hipMemcpy(n->params, host, cnt * 4, hipMemcpyHostToDevice));
+    return GRL_OK;
+}
+
+static int get_flat(grl_net *n, const float *src, float *host, int64_t cnt) {
+    if (!n || !host) return GRL_E_INVALID;
+    if (cnt != ConvOffsets::total) return nfail(n, GRL_E_SIZE, "expected " + std::to_string((long)ConvOffsets::total) + " floats");
+    hipSetDevice(n->h->cfg.device_id);
+    NET_HIP(n, hipStreamSynchronize(n->h->stream));
+    NET_HIP(n, hipMemcpy(host, src, cnt * 4, hipMemcpyDeviceToHost));
+    return GRL_OK;
+}
+int grl_net_get_params(grl_net *n, float *host, int64_t cnt) { return get_flat(n, n ? n->params : nullptr, host, cnt); }
+int grl_net_get_grads(grl_net *n, float *host, int64_t cnt) { return get_flat(n, n ? n->grads : nullptr, host, cnt); }
+
+static int download_heads(grl_net *n, int B, float *mu_host, float *sigma_host, float *vs_host) {
+    NET_HIP(n, hipStreamSynchronize(n->h->stream));
+    if (mu_host) NET_HIP(n, hipMemcpy(mu_host, n->mu, (size_t)B * 8, hipMemcpyDeviceToHost));
+    if (sigma_host) NET_HIP(n, hipMemcpy(sigma_host, n->sigma, (size_t)B * 8, hipMemcpyDeviceToHost));
+    if (vs_host) NET_HIP(n, hipMemcpy(vs_host, n->vs, (size_t)B * 4, hipMemcpyDeviceToHost));
+    return GRL_OK;
+}
+
+int grl_net_predict(grl_net *n, float *mu_host, float *sigma_host, float *vs_host) {
+    if (!n) return GRL_E_INVALID;
+    hipSetDevice(n->h->cfg.device_id);
+    grl_handle *h = n->h;
+    int rc = forward_all(n, h->sw.lbins, h->sw.abins, h->sw.pos, h->E, n->mu, n->sigma, n->vs);
+    if (rc) return rc;
+    return download_heads(n, h->E * 10, mu_host, sigma_host, vs_host);
+}
+
+int grl_net_predict_obs(grl_net *n, int32_t n_envs, const uint8_t *lb, const uint8_t *ab, const uint8_t *pos, float *mu_host,
+                        float *sigma_host, float *vs_host) {
+    if (!n || !lb || !ab || !pos || n_envs <= 0) return GRL_E_INVALID;
+    hipSetDevice(n->h->cfg.device_id);
+    int rc = ensure_tmp_obs(n, n_envs);
+    if (rc) return rc;
+    NET_HIP(n, hipMemcpyAsync(n->tmp_lb, lb, (size_t)n_envs * 160, hipMemcpyHostToDevice, n->h->stream));
+    NET_HIP(n, hipMemcpyAsync(n->tmp_ab, ab, (size_t)n_envs * 20, hipMemcpyHostToDevice, n->h->stream));
+    NET_HIP(n, hipMemcpyAsync(n->tmp_pos, pos, (size_t)n_envs * 20, hipMemcpyHostToDevice, n->h->stream));
+    rc = forward_all(n, n->tmp_lb, n->tmp_ab, n->tmp_pos, n_envs, n->mu, n->sigma, n->vs);
+    if (rc) return rc;
+    return download_heads(n, n_envs * 10, mu_host, sigma_host, vs_host);
+}
+
+int grl_net_read_activation(grl_net *n, const char *which, float *host, size_t bytes) {
+    if (!n || !which || !host) return GRL_E_INVALID;
+    hipSetDevice(n->h->cfg.device_id);
+    std::string w(which);
+    const float *src = nullptr;
+    size_t per = 0;
+    if (w == "a1") { src = n->a1; per = 12800; }
+    else if (w == "a2") { src = n->a2; per = 5184; }
+    else if (w == "a3") { src = n->a3; per = 3136; }
+    else if (w == "d1") { src = n->d1; per = 512; }
+    else if (w == "d2") { src = n->d2; per = 256; }
+    else if (w == "p1") { src = n->p1; per = 512; }
+    else if (w == "v1") { src = n->v1; per = 512; }
+    else if (w == "v2") { src = n->v2; per = 256; }
+    else return nfail(n, GRL_E_INVALID, "grl_net_read_activation: unknown tensor '" + w + "'");
+    size_t need = (size_t)n->last_n * per * 4;
+    if (bytes != need) return nfail(n, GRL_E_SIZE, "grl_net_read_activation: need " + std::to_string(need) + " bytes");
+    NET_HIP(n, hipStreamSynchronize(n->h->stream));
+    NET_HIP(n, hipMemcpy(host, src, bytes, hipMemcpyDeviceToHost));
+    return GRL_OK;
+}
+
+int grl_net_profile_enable(grl_net *n, int32_t on) {
+    if (!n) return GRL_E_INVALID;
+    hipSetDevice(n->h->cfg.device_id);
+    NET_HIP(n, hipStreamSynchronize(n->h->stream));
+    if (on && n->prof_ev.empty()) {
+        n->prof_ev.resize(16384);
+        for (auto &ev : n->prof_ev) NET_HIP(n, hipEventCreate(&ev));
+    }
+    n->prof_on = on != 0; n->prof_used = 0; n->prof_flops = 0;
+    return GRL_OK;
+}
+
+int grl_net_profile_read(grl_net *n, int32_t *launches_out, float *total_ms_out, double *flops_out) {
+    if (!n || !launches_out || !total_ms_out || !flops_out) return GRL_E_INVALID;
+    hipSetDevice(n->h->cfg.device_id);
+    NET_HIP(n, hipStreamSynchronize(n->h->stream));
+    float total = 0.f;
+    for (size_t i = 0; i + 1 < n->prof_used; i += 2) {
+        float ms = 0.f;
+        NET_HIP(n, hipEventElapsedTime(&ms, n->prof_ev[i], n->prof_ev[i + 1]));
+        total += ms;
+    }
+    *launches_out = (int32_t)(n->prof_used / 2); *total_ms_out = total; *flops_out = n->prof_flops;
+    return GRL_OK;
+}
+
+}  // extern "C"
+
+// TEMPORARY stubs (replaced by net_train.hip)
+extern "C" {
+int grl_net_rollout(grl_net *n, int32_t, int32_t) { return grl::nfail(n, GRL_E_INVALID, "not implemented"); }
+int grl_net_train_rollout(grl_net *n, float, float *) { return grl::nfail(n, GRL_E_INVALID, "not implemented"); }
+int grl_net_train_obs(grl_net *n, int32_t, const uint8_t *, const uint8_t *, const uint8_t *, const float *, const float *, const float *, float, int32_t, float *) { return grl::nfail(n, GRL_E_INVALID, "not implemented"); }
+int grl_net_read_rollout(grl_net *n, const char *, void *, size_t) { return grl::nfail(n, GRL_E_INVALID, "not implemented"); }
+}

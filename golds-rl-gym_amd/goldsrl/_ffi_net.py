@@ -1,0 +1,168 @@
+"""ctypes binding of the estimator side of libgoldsrl.so (C ABI: include/goldsrl_net.h)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+
+_P, _I, _F, _SZ = C.c_void_p, C.c_int32, C.c_float, C.c_size_t
+
+
+class GrlNetConfig(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("kind", C.c_int32), ("max_chunk_samples", C.c_int32), ("reserved", C.c_int32),
+                ("scale", C.c_float), ("entropy_beta", C.c_float), ("clip_norm", C.c_float), ("gamma", C.c_float)]
+
+
+NET_SIGNATURES = {
+    "grl_net_config_default": (C.c_int, [_I, C.POINTER(GrlNetConfig)]),
+    "grl_net_create": (C.c_int, [_P, C.POINTER(GrlNetConfig), C.POINTER(_P)]),
+    "grl_net_destroy": (C.c_int, [_P]),
+    "grl_net_last_error": (C.c_char_p, [_P]),
+    "grl_net_num_params": (C.c_int64, [_P]),
+    "grl_net_set_params": (C.c_int, [_P, _P, C.c_int64]),
+    "grl_net_get_params": (C.c_int, [_P, _P, C.c_int64]),
+    "grl_net_get_grads": (C.c_int, [_P, _P, C.c_int64]),
+    "grl_net_predict": (C.c_int, [_P, _P, _P, _P]),
+    "grl_net_predict_obs": (C.c_int, [_P, _I, _P, _P, _P, _P, _P, _P]),
+    "grl_net_rollout": (C.c_int, [_P, _I, _I]),
+    "grl_net_train_rollout": (C.c_int, [_P, _F, _P]),
+    "grl_net_train_obs": (C.c_int, [_P, _I, _P, _P, _P, _P, _P, _P, _F, _I, _P]),
+    "grl_net_read_rollout": (C.c_int, [_P, C.c_char_p, _P, _SZ]),
+    "grl_net_read_activation": (C.c_int, [_P, C.c_char_p, _P, _SZ]),
+    "grl_net_profile_enable": (C.c_int, [_P, _I]),
+    "grl_net_profile_read": (C.c_int, [_P, C.POINTER(_I), C.POINTER(C.c_float), C.POINTER(C.c_double)]),
+}
+
+NET_CONV_SINGLE_AGENT = 0
+
+# (name, shape) in flat-vector order == tf.trainable_variables() creation order
+# (reference fed_gym/agents/paac/policy_v_network.py:14-59)
+CONV_PARAM_SHAPES = [
+    ("conv1_w", (8, 8, 3, 32)), ("conv1_b", (32,)), ("conv2_w", (4, 4, 32, 64)), ("conv2_b", (64,)),
+    ("conv3_w", (3, 3, 64, 64)), ("conv3_b", (64,)), ("dense1_w", (3136, 512)), ("dense1_b", (512,)),
+    ("dense2_w", (512, 256)), ("dense2_b", (256,)), ("pol1_w", (256, 512)), ("pol1_b", (512,)),
+    ("mu_w", (512, 2)), ("mu_b", (2,)), ("sigma_w", (512, 2)), ("sigma_b", (2,)),
+    ("v1_w", (256, 512)), ("v1_b", (512,)), ("v2_w", (512, 256)), ("v2_b", (256,)), ("v3_w", (256, 1)), ("v3_b", (1,)),
+]
+
+
+def glorot_uniform_flat(seed=3):
+    """tf.layers defaults: glorot-uniform kernels, zero biases -> flat float32 vector."""
+    rng = np.random.RandomState(seed)
+    parts = []
+    for name, shape in CONV_PARAM_SHAPES:
+        if name.endswith("_w"):
+            if len(shape) == 2:
+                fan_in, fan_out = shape
+            else:
+                rf = int(np.prod(shape[:-2]))
+                fan_in, fan_out = rf * shape[-2], rf * shape[-1]
+            lim = np.sqrt(6.0 / (fan_in + fan_out))
+            parts.append(rng.uniform(-lim, lim, size=shape).reshape(-1))
+        else:
+            parts.append(np.zeros(int(np.prod(shape))))
+    return np.concatenate(parts).astype(np.float32)
+
+
+class ConvNet(object):
+    """ConvSingleAgentPolicyNetwork on the device of a Swarm Engine."""
+
+    def __init__(self, engine, **kw):
+        self.lib = _ffi.load_library(extra_signatures=NET_SIGNATURES)
+        self.eng = engine
+        cfg = GrlNetConfig()
+        rc = self.lib.grl_net_config_default(NET_CONV_SINGLE_AGENT, C.byref(cfg))
+        if rc != _ffi.OK:
+            raise _ffi.GrlError(rc, "grl_net_config_default")
+        for k, v in kw.items():
+            if not hasattr(cfg, k):
+                raise TypeError("unknown grl_net_config field %r" % k)
+            setattr(cfg, k, v)
+        self.cfg = cfg
+        n = C.c_void_p()
+        rc = self.lib.grl_net_create(engine.h, C.byref(cfg), C.byref(n))
+        if rc != _ffi.OK:
+            raise _ffi.GrlError(rc, self.lib.grl_last_error(engine.h).decode())
+        self.n = n
+        self.num_params = int(self.lib.grl_net_num_params(n))
+
+    def _check(self, rc):
+        if rc != _ffi.OK:
+            raise _ffi.GrlError(rc, self.lib.grl_net_last_error(self.n).decode())
+
+    def close(self):
+        if getattr(self, "n", None):
+            self.lib.grl_net_destroy(self.n)
+            self.n = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_params(self, flat):
+        a = np.ascontiguousarray(flat, dtype=np.float32)
+        self._check(self.lib.grl_net_set_params(self.n, _ffi._ptr(a), a.size))
+
+    def get_params(self):
+        a = np.empty(self.num_params, np.float32)
+        self._check(self.lib.grl_net_get_params(self.n, _ffi._ptr(a), a.size))
+        return a
+
+    def get_grads(self):
+        a = np.empty(self.num_params, np.float32)
+        self._check(self.lib.grl_net_get_grads(self.n, _ffi._ptr(a), a.size))
+        return a
+
+    def predict(self):
+        B = self.eng.E * 10
+        mu, sg, vs = np.empty((B, 2), np.float32), np.empty((B, 2), np.float32), np.empty(B, np.float32)
+        self._check(self.lib.grl_net_predict(self.n, _ffi._ptr(mu), _ffi._ptr(sg), _ffi._ptr(vs)))
+        return {"mu": mu, "sigma": sg, "vs": vs}
+
+    def predict_obs(self, locust_bins, agent_bins, positions):
+        lb = np.ascontiguousarray(locust_bins, np.uint8); ab = np.ascontiguousarray(agent_bins, np.uint8)
+        ps = np.ascontiguousarray(positions, np.uint8)
+        ne = lb.shape[0]
+        B = ne * 10
+        mu, sg, vs = np.empty((B, 2), np.float32), np.empty((B, 2), np.float32), np.empty(B, np.float32)
+        self._check(self.lib.grl_net_predict_obs(self.n, ne, _ffi._ptr(lb), _ffi._ptr(ab), _ffi._ptr(ps), _ffi._ptr(mu),
+                                                 _ffi._ptr(sg), _ffi._ptr(vs)))
+        return {"mu": mu, "sigma": sg, "vs": vs}
+
+    def train_obs(self, locust_bins, agent_bins, positions, actions, advantages, critic_target, lr, apply_update=True):
+        lb = np.ascontiguousarray(locust_bins, np.uint8); ab = np.ascontiguousarray(agent_bins, np.uint8)
+        ps = np.ascontiguousarray(positions, np.uint8)
+        a = np.ascontiguousarray(actions, np.float32); adv = np.ascontiguousarray(advantages, np.float32)
+        y = np.ascontiguousarray(critic_target, np.float32)
+        stats = np.zeros(4, np.float32)
+        self._check(self.lib.grl_net_train_obs(self.n, lb.shape[0], _ffi._ptr(lb), _ffi._ptr(ab), _ffi._ptr(ps), _ffi._ptr(a),
+                                               _ffi._ptr(adv), _ffi._ptr(y), lr, 1 if apply_update else 0, _ffi._ptr(stats)))
+        return dict(zip(("loss", "policy_loss", "critic_loss_mean", "global_norm"), stats.tolist()))
+
+    def rollout(self, T, reward_layout=0):
+        self._check(self.lib.grl_net_rollout(self.n, T, reward_layout))
+
+    def train_rollout(self, lr):
+        stats = np.zeros(4, np.float32)
+        self._check(self.lib.grl_net_train_rollout(self.n, lr, _ffi._ptr(stats)))
+        return dict(zip(("loss", "policy_loss", "critic_loss_mean", "global_norm"), stats.tolist()))
+
+    def read_rollout(self, which, shape, dtype=np.float32):
+        a = np.empty(shape, dtype)
+        self._check(self.lib.grl_net_read_rollout(self.n, which.encode(), _ffi._ptr(a), a.nbytes))
+        return a
+
+    def read_activation(self, which, shape):
+        a = np.empty(shape, np.float32)
+        self._check(self.lib.grl_net_read_activation(self.n, which.encode(), _ffi._ptr(a), a.nbytes))
+        return a
+
+    def profile_enable(self, on=True):
+        self._check(self.lib.grl_net_profile_enable(self.n, 1 if on else 0))
+
+    def profile_read(self):
+        n, ms, fl = C.c_int32(), C.c_float(), C.c_double()
+        self._check(self.lib.grl_net_profile_read(self.n, C.byref(n), C.byref(ms), C.byref(fl)))
+        return n.value, ms.value, fl.value

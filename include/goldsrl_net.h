@@ -1,0 +1,88 @@
+/* goldsrl_net.h -- C ABI of the policy/value estimator side of libgoldsrl.so.
+ *
+ * Replaces (paths relative to the reference repo root):
+ *   fed_gym/agents/paac/policy_v_network.py:5-80     ConvSingleAgentPolicyNetwork (+ predict())
+ *   fed_gym/agents/paac/networks.py:100-167          placeholder contract (states/actions/advantages/critic_target)
+ *   fed_gym/agents/paac/paac.py:408-419              choose_next_actions: a = mu + sigma*N(0,1)
+ *   fed_gym/agents/paac/actor_learner.py:31-68,115-119  Adam, clip_by_global_norm, lr anneal
+ * Conventions as in goldsrl.h.  A net is bound to the device/stream of the grl_handle it was
+ * created on.  Parameters are one flat float32 vector in tf.trainable_variables() creation order:
+ *   conv1_w[8,8,3,32] conv1_b conv2_w[4,4,32,64] conv2_b conv3_w[3,3,64,64] conv3_b dense1_w[3136,512]
+ *   dense1_b dense2_w[512,256] dense2_b pol1_w[256,512] pol1_b mu_w[512,2] mu_b sigma_w[512,2] sigma_b
+ *   v1_w[256,512] v1_b v2_w[512,256] v2_b v3_w[256,1] v3_b                          (2 210 213 floats)
+ */
+#ifndef GOLDSRL_NET_H
+#define GOLDSRL_NET_H
+
+#include "goldsrl.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GRL_NET_CONV_SINGLE_AGENT 0 /* policy_v_network.py:5-66; Swarm handles only */
+
+typedef struct grl_net_config {
+    int32_t struct_size;
+    int32_t kind;              /* GRL_NET_* */
+    int32_t max_chunk_samples; /* agent-samples processed per pass; activations are sized for this (multiple of 10) */
+    int32_t reserved;
+    float scale;               /* conf['scale'] (train_paac_conv.py --scale, 1000) */
+    float entropy_beta;        /* conf['entropy_regularisation_strength'] (0.02) */
+    float clip_norm;           /* --clip_norm (40), clip_norm_type 'global'; <= 0 means 'ignore' */
+    float gamma;               /* --gamma (0.99) */
+} grl_net_config;
+
+typedef struct grl_net grl_net;
+
+int grl_net_config_default(int32_t kind, grl_net_config *cfg);
+int grl_net_create(grl_handle *h, const grl_net_config *cfg, grl_net **out);
+int grl_net_destroy(grl_net *net);
+const char *grl_net_last_error(const grl_net *net);
+int64_t grl_net_num_params(const grl_net *net);
+int grl_net_set_params(grl_net *net, const float *host, int64_t n);
+int grl_net_get_params(grl_net *net, float *host, int64_t n);
+int grl_net_get_grads(grl_net *net, float *host, int64_t n);   /* flat gradient of the last grl_net_train call (before clipping) */
+
+/* network.predict(states) (policy_v_network.py:69-80) on the CURRENT observation of the Swarm
+ * handle: B = 10*num_envs agent-samples in env-major order.  Outputs are HOST arrays (may be NULL):
+ * mu (B,2) sigma (B,2) vs (B,).  Synchronous. */
+int grl_net_predict(grl_net *net, float *mu_host, float *sigma_host, float *vs_host);
+/* Same on caller-supplied compact observations (host): locust_bins (n_envs,80,2) agent_bins (n_envs,10,2)
+ * positions (n_envs,10,2), all uint8 as in grl_out_ptrs. */
+int grl_net_predict_obs(grl_net *net, int32_t n_envs, const uint8_t *locust_bins, const uint8_t *agent_bins,
+                        const uint8_t *positions, float *mu_host, float *sigma_host, float *vs_host);
+
+/* One PAAC rollout entirely on the device (GridPAACLearner.train inner loop, paac.py:302-372):
+ * T x [forward, a = mu + sigma*N(0,1), SwarmRunner norm clip, env step/auto-reset/observe], bootstrap
+ * forward, n-step returns/advantages.  Buffers stay on the device for grl_net_train_rollout().
+ * reward_layout: 0 = every agent column receives its env's reward ("broadcast"),
+ *                1 = the reference's indexing (paac.py:331-338, quirk Q4).
+ * Asynchronous: enqueues on the handle's stream; grl_wait(h) joins. */
+int grl_net_rollout(grl_net *net, int32_t T, int32_t reward_layout);
+/* Gradient step on the last rollout's T*B samples: loss (policy_v_network.py:45-66), backward,
+ * [all-reduce over ranks if a communicator is attached], clip_by_global_norm, Adam(lr).
+ * stats_host (may be NULL) receives {loss, policy_loss, critic_loss_mean, global_norm}. Synchronous. */
+int grl_net_train_rollout(grl_net *net, float lr, float *stats_host);
+/* Gradient step on caller-supplied samples (tests; network.loss feed of paac.py:374-387):
+ * compact observations for n_envs envs (n = 10*n_envs samples), actions (n,2), advantages (n,)
+ * ALREADY divided by scale, critic_target (n,).  apply_update=0 only computes gradients. */
+int grl_net_train_obs(grl_net *net, int32_t n_envs, const uint8_t *locust_bins, const uint8_t *agent_bins,
+                      const uint8_t *positions, const float *actions, const float *advantages,
+                      const float *critic_target, float lr, int32_t apply_update, float *stats_host);
+/* Copy one rollout buffer to the host: "actions" (T,B,2) raw sampled actions, "values" (T,B),
+ * "rewards" (T,B), "y" (T,B), "adv" (T,B), "boot" (B,). */
+int grl_net_read_rollout(grl_net *net, const char *which, void *host, size_t bytes);
+/* Debug/test access to a forward activation of the last chunk: "a1" (n,20,20,32) "a2" (n,9,9,64)
+ * "a3" (n,7,7,64) "d1" (n,512) "d2" (n,256) "p1" (n,512) "v1" (n,512) "v2" (n,256). */
+int grl_net_read_activation(grl_net *net, const char *which, float *host, size_t bytes);
+
+/* Per-kernel timing of the GEMM kernels for bench.py's roofline (HIP events around every launch
+ * of gemm_rowk / gemm_tn while enabled): returns launches, summed ms and summed FLOPs. */
+int grl_net_profile_enable(grl_net *net, int32_t on);
+int grl_net_profile_read(grl_net *net, int32_t *launches_out, float *total_ms_out, double *flops_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GOLDSRL_NET_H */
