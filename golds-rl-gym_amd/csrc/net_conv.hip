@@ -7,6 +7,7 @@
 // ~12k instead of 2.46M multiply-adds -- by one workgroup per env that stages the 84x84 count
 // grids in LDS, builds the pre-activation shared by the env's 10 agents once, and adds each
 // agent's one-hot tap.  conv2/conv3/dense layers are fp32-MFMA implicit GEMMs (net_gemm.h).
+#include <rccl/rccl.h>
 #include <string.h>
 
 #include <cmath>
@@ -70,6 +71,8 @@ struct grl_net {
     size_t prof_used;
     double prof_flops;
     int last_n;                // samples in the last chunk (for read_activation)
+    void *comm;                // ncclComm_t (RCCL) for the per-rollout gradient all-reduce, or nullptr
+    int comm_world, comm_rank;
 };
 
 namespace grl {
@@ -346,6 +349,7 @@ int grl_net_destroy(grl_net *n) {
     if (!n) return GRL_OK;
     hipSetDevice(n->h->cfg.device_id);
     hipStreamSynchronize(n->h->stream);
+    if (n->comm) ncclCommDestroy((ncclComm_t)n->comm);
     for (void *p : n->allocs) hipFree(p);
     for (hipEvent_t ev : n->prof_ev) hipEventDestroy(ev);
     delete n;
@@ -456,10 +460,4 @@ int grl_net_profile_read(grl_net *n, int32_t *launches_out, float *total_ms_out,
 
 }  // extern "C"
 
-// TEMPORARY stubs (replaced by net_train.hip)
-extern "C" {
-int grl_net_rollout(grl_net *n, int32_t, int32_t) { return grl::nfail(n, GRL_E_INVALID, "not implemented"); }
-int grl_net_train_rollout(grl_net *n, float, float *) { return grl::nfail(n, GRL_E_INVALID, "not implemented"); }
-int grl_net_train_obs(grl_net *n, int32_t, const uint8_t *, const uint8_t *, const uint8_t *, const float *, const float *, const float *, float, int32_t, float *) { return grl::nfail(n, GRL_E_INVALID, "not implemented"); }
-int grl_net_read_rollout(grl_net *n, const char *, void *, size_t) { return grl::nfail(n, GRL_E_INVALID, "not implemented"); }
-}
+#include "net_train.inc"

@@ -332,13 +332,23 @@ __global__ void slab_reduce_kernel(const float *__restrict__ slab, int chunks, l
 }
 
 // column sums of dY[M][J] over row chunks -> slab[chunk][J]   (bias gradients)
-__global__ void colsum_kernel(const float *__restrict__ dY, int M, int J, int mc, float *__restrict__ slab) {
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= J) return;
-    int mbeg = blockIdx.y * mc, mend = min(M, mbeg + mc);
+// 256 threads: min(J,256) column lanes x (256/J) row lanes, row lanes combined through LDS in a fixed order
+__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ dY, int M, int J, int mc, float *__restrict__ slab) {
+    __shared__ float red[256];
+    const int jw = J < 256 ? J : 256;            // J is a power of two >= 32 or a multiple of 256
+    const int rl = 256 / jw;
+    const int jl = threadIdx.x % jw, rsub = threadIdx.x / jw;
+    const int j = blockIdx.x * jw + jl;
+    const int mbeg = blockIdx.y * mc, mend = min(M, mbeg + mc);
     float s = 0.f;
-    for (int m = mbeg; m < mend; ++m) s += dY[(long)m * J + j];
-    slab[(long)blockIdx.y * J + j] = s;
+    if (j < J)
+        for (int m = mbeg + rsub; m < mend; m += rl) s += dY[(long)m * J + j];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (rsub == 0 && j < J) {
+        for (int r = 1; r < rl; ++r) s += red[r * jw + jl];
+        slab[(long)blockIdx.y * J + j] = s;
+    }
 }
 
 }  // namespace grl

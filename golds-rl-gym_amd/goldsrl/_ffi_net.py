@@ -29,6 +29,11 @@ NET_SIGNATURES = {
     "grl_net_train_obs": (C.c_int, [_P, _I, _P, _P, _P, _P, _P, _P, _F, _I, _P]),
     "grl_net_read_rollout": (C.c_int, [_P, C.c_char_p, _P, _SZ]),
     "grl_net_read_activation": (C.c_int, [_P, C.c_char_p, _P, _SZ]),
+    "grl_comm_unique_id_bytes": (C.c_size_t, []),
+    "grl_comm_unique_id": (C.c_int, [_P, _SZ]),
+    "grl_net_comm_init": (C.c_int, [_P, _P, _SZ, _I, _I]),
+    "grl_net_comm_broadcast_params": (C.c_int, [_P, _I]),
+    "grl_net_comm_destroy": (C.c_int, [_P]),
     "grl_net_profile_enable": (C.c_int, [_P, _I]),
     "grl_net_profile_read": (C.c_int, [_P, C.POINTER(_I), C.POINTER(C.c_float), C.POINTER(C.c_double)]),
 }
@@ -158,6 +163,22 @@ class ConvNet(object):
         a = np.empty(shape, np.float32)
         self._check(self.lib.grl_net_read_activation(self.n, which.encode(), _ffi._ptr(a), a.nbytes))
         return a
+
+    # -- multi-GPU (RCCL): rank 0 makes the id, everybody attaches
+    def comm_unique_id(self):
+        n = int(self.lib.grl_comm_unique_id_bytes())
+        buf = np.zeros(n, np.uint8)
+        rc = self.lib.grl_comm_unique_id(_ffi._ptr(buf), n)
+        if rc != _ffi.OK:
+            raise _ffi.GrlError(rc, "grl_comm_unique_id")
+        return buf
+
+    def comm_init(self, unique_id, rank, world_size):
+        buf = np.ascontiguousarray(unique_id, np.uint8)
+        self._check(self.lib.grl_net_comm_init(self.n, _ffi._ptr(buf), buf.size, rank, world_size))
+
+    def comm_broadcast_params(self, root=0):
+        self._check(self.lib.grl_net_comm_broadcast_params(self.n, root))
 
     def profile_enable(self, on=True):
         self._check(self.lib.grl_net_profile_enable(self.n, 1 if on else 0))

@@ -77,6 +77,17 @@ int grl_net_read_rollout(grl_net *net, const char *which, void *host, size_t byt
  * "a3" (n,7,7,64) "d1" (n,512) "d2" (n,256) "p1" (n,512) "v1" (n,512) "v2" (n,256). */
 int grl_net_read_activation(grl_net *net, const char *which, float *host, size_t bytes);
 
+/* ---- multi-GPU: one process per GPU, one RCCL all-reduce (sum, fp32) of the flat gradient per
+ * rollout over xGMI (no counterpart in the reference, which is single-device: actor_learner.py:70-75).
+ * Rank 0 calls grl_comm_unique_id and ships the bytes to the other ranks by any means (bench.py uses
+ * torch.distributed/gloo broadcast); every rank then calls grl_net_comm_init.  Afterwards
+ * grl_net_train_* all-reduces gradients before clip+Adam, so parameters stay replicated. */
+size_t grl_comm_unique_id_bytes(void);
+int grl_comm_unique_id(void *out, size_t bytes);
+int grl_net_comm_init(grl_net *net, const void *unique_id, size_t bytes, int32_t rank, int32_t world_size);
+int grl_net_comm_broadcast_params(grl_net *net, int32_t root);
+int grl_net_comm_destroy(grl_net *net);
+
 /* Per-kernel timing of the GEMM kernels for bench.py's roofline (HIP events around every launch
  * of gemm_rowk / gemm_tn while enabled): returns launches, summed ms and summed FLOPs. */
 int grl_net_profile_enable(grl_net *net, int32_t on);

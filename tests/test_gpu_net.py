@@ -70,3 +70,95 @@ def test_conv_forward_zero_bias_default_init():
     mu, sigma, vs = NN.conv_forward(p, states, 1000.0)
     np.testing.assert_allclose(out["mu"], mu, rtol=2e-5, atol=2e-6)
     np.testing.assert_allclose(out["vs"], vs, rtol=2e-5, atol=1e-3)
+
+
+def _train_inputs(E, seed=1):
+    rng = np.random.RandomState(seed)
+    n = E * 10
+    return rng.normal(size=(n, 2)).astype(np.float32) * 0.7, (rng.normal(size=n) * 0.02).astype(np.float32), \
+        (-rng.rand(n) * 400).astype(np.float32)
+
+
+def test_conv_gradients_match_oracle():
+    E = 6      # 60 samples, chunk 40: gradients accumulate over two chunks
+    eng, net, p, states, obs = _setup(E)
+    act, adv, y = _train_inputs(E)
+    stats = net.train_obs(*obs, act, adv, y, lr=0.0, apply_update=False)
+    loss, pl, cl, g, _ = NN.conv_loss_and_grads(p, states, act.astype(np.float64), adv.astype(np.float64), y.astype(np.float64), 0.02, 1000.0)
+    np.testing.assert_allclose(stats["loss"], loss, rtol=1e-4)
+    np.testing.assert_allclose(stats["policy_loss"], pl, rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(stats["critic_loss_mean"], cl, rtol=1e-4)
+    got = NN.unflatten_params(net.get_grads().astype(np.float64))
+    for name, _ in NN.CONV_PARAM_SHAPES:
+        ref = g[name]
+        scale = np.abs(ref).max() + 1e-12
+        err = np.abs(got[name] - ref).max() / scale
+        assert err < 2e-4, (name, err)
+    gn = np.sqrt(sum((g[k] ** 2).sum() for k in g))
+    np.testing.assert_allclose(stats["global_norm"], gn, rtol=1e-4)
+    # bitwise reproducible: the same call again gives the same gradient
+    first = net.get_grads()
+    net.train_obs(*obs, act, adv, y, lr=0.0, apply_update=False)
+    assert np.array_equal(first, net.get_grads())
+
+
+def test_adam_step_with_global_norm_clip_matches_oracle():
+    E = 4
+    eng, net, p, states, obs = _setup(E)
+    from goldsrl import _ffi_net
+    net2 = _ffi_net.ConvNet(eng, max_chunk_samples=40, clip_norm=0.5)     # force clipping
+    flat0 = NN.flatten_params(p)
+    net2.set_params(flat0.astype(np.float32))
+    act, adv, y = _train_inputs(E, seed=2)
+    pf, m, v = flat0.copy(), np.zeros_like(flat0), np.zeros_like(flat0)
+    for step in range(1, 4):
+        pp = NN.unflatten_params(pf)
+        _, _, _, g, _ = NN.conv_loss_and_grads(pp, states, act.astype(np.float64), adv.astype(np.float64), y.astype(np.float64), 0.02, 1000.0)
+        gf, norm = NN.clip_by_global_norm(NN.flatten_params(g), 0.5)
+        pf, m, v = NN.adam_step(pf, gf, m, v, step, 1e-3)
+        st = net2.train_obs(*obs, act, adv, y, lr=1e-3, apply_update=True)
+        np.testing.assert_allclose(st["global_norm"], norm, rtol=2e-4)
+        assert norm > 0.5
+        got = net2.get_params().astype(np.float64)
+        # Adam's first steps move every weight by ~lr: compare the UPDATE, not just the weights
+        np.testing.assert_allclose(got - flat0, pf - flat0, rtol=0, atol=3e-5 * step)
+        assert np.abs(got - flat0).max() > 5e-4
+
+
+def test_device_rollout_matches_oracle_pieces():
+    E, T = 8, 5
+    eng, net, p, states, obs = _setup(E)
+    B = E * 10
+    x0, xa0 = eng.get_state("SWARM_X"), eng.get_state("SWARM_XA")
+    pn, an = eng.get_state("SWARM_PNOISE"), eng.get_state("SWARM_ANOISE")
+    pred = net.predict()
+    net.rollout(T, 0)
+    eng.wait()
+    acts = net.read_rollout("actions", (T, B, 2)); vals = net.read_rollout("values", (T, B)); rews = net.read_rollout("rewards", (T, B))
+    yy = net.read_rollout("y", (T, B)); adv = net.read_rollout("adv", (T, B)); boot = net.read_rollout("boot", (B,))
+    # t=0: values and actions come from the net's prediction on the initial observation
+    assert np.array_equal(vals[0], pred["vs"])
+    env = np.arange(E)
+    e0, e1 = O.normal_pair(O.rng_block(11, env[:, None], 0, 16, np.arange(10)[None]))
+    eps = np.stack([e0, e1], axis=-1).reshape(B, 2)
+    np.testing.assert_allclose(acts[0], pred["mu"].astype(np.float64) + pred["sigma"].astype(np.float64) * eps, rtol=1e-6, atol=1e-7)
+    # the env stepped with the norm-clipped action: replay step 0 on the oracle
+    a_env = O.swarm_transform_actions(acts[0]).reshape(E, 10, 2)
+    ox, oxa, orew, _ = O.swarm_step(x0, xa0, a_env.astype(np.float64), an, pn)
+    np.testing.assert_allclose(rews[0].reshape(E, 10), np.repeat(orew[:, None], 10, 1), rtol=1e-6)
+    # observations stored per step feed the same net: values[t] == predict_obs(stored obs[t])
+    lb = net.read_rollout("locust_bins", (T, E, 80, 2), np.uint8); ab = net.read_rollout("agent_bins", (T, E, 10, 2), np.uint8)
+    ps = net.read_rollout("positions", (T, E, 10, 2), np.uint8)
+    assert np.array_equal(net.predict_obs(lb[3], ab[3], ps[3])["vs"], vals[3])
+    # returns/advantages: GridPAACLearner form (unmasked, unclipped, adv/scale)
+    oy, oadv = O.nstep_returns(rews.astype(np.float64), vals, boot, 0.99)
+    np.testing.assert_allclose(yy, oy, rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(adv, oadv / 1000.0, rtol=1e-5, atol=1e-6)
+    # quirk Q4 layout: only the first E columns receive rewards
+    net.rollout(2, 1)
+    eng.wait()
+    r1 = net.read_rollout("rewards", (2, B))
+    assert (r1[:, E:] == 0).all() and (r1[:, :E] < 0).all()
+    # and one training step on the rollout runs and reports finite numbers
+    st = net.train_rollout(1e-4)
+    assert all(np.isfinite(list(st.values()))) and st["global_norm"] > 0
