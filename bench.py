@@ -1,16 +1,22 @@
 #!/usr/bin/env python3
-"""bench.py -- env-steps/s of the PAAC rollout hot path on N MI355X GPUs of one node.
+"""bench.py -- env-steps/s of the PAAC hot path on N MI355X GPUs of one node.
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 it is launched by
 torch.distributed.run, one rank per GPU.  Prints ONE JSON line on rank 0.
 
-A "step" is one T=20-step PAAC rollout over this rank's shard of Swarm-v0 envs (BASELINE config 3:
-32 768 envs per GPU, 84x84 observation): per env step -> policy actions, SwarmRunner norm clip,
-SwarmEnv.step, TimeLimit, auto-reset, process_state; then n-step returns/advantages.  Everything
-is resident in HBM when the timed region starts; nothing crosses PCIe inside it.
+A "step" is one full PAAC update of GridPAACLearner (reference paac.py:302-387) on this rank's shard
+of Swarm-v0 envs (BASELINE configs[2]: 32 768 envs per GPU, 84x84x3 observation, T=20):
+  T x [ConvSingleAgentPolicyNetwork forward on E*10 agent images, a = mu + sigma*N(0,1), norm clip,
+       SwarmEnv.step, TimeLimit, auto-reset, process_state]  + bootstrap forward + n-step returns
+  + loss/backward over the T*E*10 samples + [RCCL all-reduce of the gradient] + clip + Adam.
+Everything is resident in HBM when the timed region starts; nothing crosses PCIe inside it.
+`value` = env-steps/s of that full update (policy forward AND training included).  The same JSON
+line also carries, measured in the same run: `rollout_only` (no training) and `env_only` (random
+Gaussian policy: the env/observation/returns kernels alone).
 
-Envs are independent, so N GPUs shard the env batch (global env ids key the generator, results do
-not depend on N) with no data-path collective: scaling = weak (32 768 envs per GPU).
+Envs are independent, so N GPUs shard the env batch (global env ids key the generators; results do
+not depend on N); the only collective is one all-reduce of the 2.2M-float gradient per update.
+scaling = weak (32 768 envs per GPU).
 """
 import argparse
 import json
@@ -28,18 +34,22 @@ for p in (ROOT, os.path.join(ROOT, "golds-rl-gym_amd")):
 SWARM_BYTES_PER_ENV_STEP = 4613      # algorithmic HBM bytes of one Swarm env-step
 SWARM_PAIRS_PER_ENV_STEP = 7200      # pair interactions (6400 locust-locust + 800 agent-locust)
 HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3         # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--envs", type=int, default=32768, help="Swarm envs per GPU")
     ap.add_argument("--T", type=int, default=20, help="max_local_steps")
-    ap.add_argument("--policy", default="auto", choices=["auto", "random", "conv"])
+    ap.add_argument("--policy", default="conv", choices=["conv", "random"],
+                    help="conv: the full PAAC update (default); random: env-only rollout")
+    ap.add_argument("--no-train", action="store_true", help="conv policy rollout without the gradient step")
     ap.add_argument("--fast-math", action="store_true", help="GRL_F_SWARM_FAST_MATH (not the parity default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the rollout_only / env_only side measurements")
     ap.add_argument("--cpu-sample-envs", type=int, default=2048)
     return ap.parse_args()
 
@@ -95,9 +105,17 @@ def cpu_baseline(sample_envs, T):
         out[label] = (E * T / dt, used, dt)
     v, used, dt = out["allcores"]
     return {"value": v, "unit": "env-steps/s", "cores": used, "kind": "port",
-            "sample": "oracle/oracle_c.c (SwarmEnv.step + process_state, float64, OpenMP) on %d envs x %d steps, %.1f s; "
-                      "1 core: %.0f env-steps/s" % (E, T, dt + out["1core"][2], out["1core"][0]),
+            "sample": "oracle/oracle_c.c (SwarmEnv.step + process_state only -- no policy network --, float64, OpenMP) on "
+                      "%d envs x %d steps, %.1f s total; 1 core: %.0f env-steps/s" % (E, T, dt + out["1core"][2], out["1core"][0]),
             "value_1core": out["1core"][0]}
+
+
+def timed(run, wait, steps):
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run()
+    wait()
+    return time.perf_counter() - t0
 
 
 def main():
@@ -107,24 +125,31 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     if world > 1:
-        import torch.distributed as dist   # rendezvous/barrier/max only; the data path never touches torch
+        import torch
+        import torch.distributed as dist   # rendezvous / barrier / max only; the data path never touches torch
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
-    from goldsrl import _ffi
-    from goldsrl import sharding
-    E = args.envs
+    from goldsrl import _ffi, sharding
+    E, T = args.envs, args.T
     off = sharding.env_id_offset(rank, E)
     flags = _ffi.F_SWARM_FAST_MATH if args.fast_math else 0
     eng = _ffi.Engine(_ffi.ENV_SWARM, E, device_id=local_rank, seed=1692, env_id_offset=off, flags=flags)
     eng.reset()
 
-    policy = "random" if args.policy == "auto" else args.policy
-    if policy == "conv":
+    net = None
+    if args.policy == "conv":
         from goldsrl import rollout as R
-        roll = R.ConvPolicyRollout(eng, args.T)
+        roll = R.ConvPolicyRollout(eng, T, train=not args.no_train)
+        net = roll.net
+        if world > 1:
+            uid = net.comm_unique_id() if rank == 0 else np.zeros(net.comm_unique_id().size, np.uint8)
+            t = torch.from_numpy(uid)
+            dist.broadcast(t, src=0)
+            net.comm_init(t.numpy(), rank, world)     # RCCL over xGMI: one gradient all-reduce per update
+            net.comm_broadcast_params(0)
     else:
-        roll = RandomPolicyRollout(eng, args.T)
+        roll = RandomPolicyRollout(eng, T)
 
     def barrier():
         eng.wait()
@@ -135,27 +160,41 @@ def main():
         roll.run()
     barrier()
     eng.profile_enable(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        roll.run()
-    eng.wait()
-    t1 = time.perf_counter()
+    if net is not None:
+        net.profile_enable(True)
+    elapsed = timed(roll.run, eng.wait, args.steps)
     if dist is not None:
         dist.barrier()
-    launches, kernel_ms = eng.profile_read()
+    env_launches, env_kernel_ms = eng.profile_read()
     eng.profile_enable(False)
-    elapsed = t1 - t0
+    gemm = net.profile_read() if net is not None else None
+    if net is not None:
+        net.profile_enable(False)
     if dist is not None:
-        import torch
         tt = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt[0])
 
+    extras = {}
+    if not args.no_extras and args.policy == "conv" and world == 1:
+        if not args.no_train:      # same net, same rollout, without the gradient step
+            roll.train = False
+            roll.run(); eng.wait()
+            dt = timed(roll.run, eng.wait, 2)
+            extras["rollout_only"] = {"value": E * T * 2 / dt, "unit": "env-steps/s", "steps": 2,
+                                      "what": "T x (conv forward + sample + env step + observe) + bootstrap + returns, no gradient step"}
+            roll.train = True
+        rr = RandomPolicyRollout(eng, T)
+        rr.run(); eng.wait()
+        dt = timed(rr.run, eng.wait, 5)
+        extras["env_only"] = {"value": E * T * 5 / dt, "unit": "env-steps/s", "steps": 5,
+                              "what": "random Gaussian policy: action draw + norm clip + env step + auto-reset + process_state + returns"}
+
     if rank == 0:
-        total_env_steps = world * E * args.T * args.steps
+        total_env_steps = world * E * T * args.steps
         value = total_env_steps / elapsed
-        k_avg_ms = kernel_ms / max(launches, 1)
-        achieved = E * SWARM_BYTES_PER_ENV_STEP / (k_avg_ms * 1e-3) / 1e9
+        k_avg_ms = env_kernel_ms / max(env_launches, 1)
+        env_achieved = E * SWARM_BYTES_PER_ENV_STEP / (k_avg_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "swarm_step_traffic.json")
         if os.path.exists(tpath):
@@ -163,23 +202,41 @@ def main():
                 tj = json.load(f)
             if tj.get("envs") == E and bool(tj.get("fast_math")) == bool(args.fast_math):
                 traffic = tj.get("hbm_bytes_per_launch")
+        env_roof = {"bound": "hbm", "kernel": "swarm_kernel<MODE_STEP>", "achieved": env_achieved, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": env_achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_kernel_ms": k_avg_ms,
+                    "launches": env_launches, "pair_interactions_per_s": E * SWARM_PAIRS_PER_ENV_STEP / (k_avg_ms * 1e-3),
+                    "note": "fp64-VALU/transcendental bound (~90 flop/B), not HBM bound: see DESIGN.md"}
+        stages = "action draw + norm clip + SwarmEnv.step + TimeLimit + auto-reset + process_state + n-step returns"
+        if args.policy == "conv":
+            stages = ("conv policy forward (fp32) + Gaussian sample + norm clip + SwarmEnv.step + TimeLimit + auto-reset + "
+                      "process_state + bootstrap + n-step returns" + ("" if args.no_train else
+                      " + loss/backward over T*E*10 samples + gradient all-reduce + clip_by_global_norm + Adam"))
         out = {
             "metric": "env-steps/sec (whole node), 32k parallel Swarm-v0 envs, 20-step PAAC rollout",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "Swarm-v0 84x84, %d envs per GPU, T=%d PAAC rollout (BASELINE configs[2])" % (E, args.T),
-                       "envs_per_gpu": E, "rollout_steps": args.T, "policy": policy,
-                       "swarm_math": "fast" if args.fast_math else "exact",
-                       "stages": "action draw + norm clip + SwarmEnv.step + TimeLimit + auto-reset + process_state + n-step returns"},
-            "roofline": {"bound": "hbm", "kernel": "swarm_kernel<MODE_STEP>", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "avg_kernel_ms": k_avg_ms, "launches": launches,
-                         "pair_interactions_per_s": E * SWARM_PAIRS_PER_ENV_STEP / (k_avg_ms * 1e-3),
-                         "note": "kernel is fp64-VALU/transcendental bound (~90 flop/B), not HBM bound: see DESIGN.md"},
+            "vs_baseline": None, "dtype": "f32" if args.policy == "conv" else "f64", "data": "synthetic",
+            "config": {"workload": "Swarm-v0 84x84, %d envs per GPU, T=%d PAAC update, conv policy of train_paac_conv.py "
+                                   "(BASELINE configs[2])" % (E, T),
+                       "envs_per_gpu": E, "rollout_steps": T, "policy": args.policy, "train": args.policy == "conv" and not args.no_train,
+                       "swarm_math": "fast" if args.fast_math else "exact", "env_state_dtype": "f64", "stages": stages},
         }
+        if gemm is not None:
+            launches, ms, flops = gemm
+            ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            out["roofline"] = {"bound": "mfma", "kernel": "gemm_rowk / gemm_tn (fp32 v_mfma_f32_32x32x2_f32 implicit GEMMs)",
+                               "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TFLOPS,
+                               "traffic": None, "launches": launches, "gemm_ms_total": ms,
+                               "gemm_share_of_step": (ms * 1e-3) / elapsed if world == 1 else None,
+                               "flops_per_launch_avg": flops / max(launches, 1)}
+            out["roofline_env_step"] = env_roof
+        else:
+            out["roofline"] = env_roof
+        out.update(extras)
+        if roll is not None and getattr(roll, "last_stats", None):
+            out["last_update_stats"] = roll.last_stats
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample_envs, args.T)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample_envs, T)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

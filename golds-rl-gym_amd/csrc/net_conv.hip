@@ -437,7 +437,7 @@ int grl_net_profile_enable(grl_net *n, int32_t on) {
     hipSetDevice(n->h->cfg.device_id);
     NET_HIP(n, hipStreamSynchronize(n->h->stream));
     if (on && n->prof_ev.empty()) {
-        n->prof_ev.resize(16384);
+        n->prof_ev.resize(131072);   // 65 536 bracketed launches (~13 full updates at 32 768 envs)
         for (auto &ev : n->prof_ev) NET_HIP(n, hipEventCreate(&ev));
     }
     n->prof_on = on != 0; n->prof_used = 0; n->prof_flops = 0;

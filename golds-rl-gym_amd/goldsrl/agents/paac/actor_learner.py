@@ -1,0 +1,38 @@
+"""ActorLearner base (reference fed_gym/agents/paac/actor_learner.py:10-124): argument plumbing, reward
+clip, linear lr anneal.  TF session / saver / summary plumbing has no counterpart."""
+
+
+class ActorLearner(object):
+    def __init__(self, network_creator, environment_creator, args, emulator_class):
+        self.global_step = 0
+        self.emulator_class = emulator_class
+        self.max_local_steps = args.max_local_steps
+        self.num_actions = args.num_actions
+        self.initial_lr = args.initial_lr
+        self.lr_annealing_steps = args.lr_annealing_steps
+        self.emulator_counts = args.emulator_counts
+        self.device = args.device
+        self.debugging_folder = args.debugging_folder
+        self.max_global_steps = args.max_global_steps
+        self.gamma = args.gamma
+        self.network_creator = network_creator
+        self.environment_creator = environment_creator
+        self.network = network_creator()
+        self.runners = None
+
+    def rescale_reward(self, reward, lb=-2, ub=2):
+        """Clip immediate reward (actor_learner.py:91-97)."""
+        if reward > ub:
+            reward = ub
+        elif reward < lb:
+            reward = lb
+        return reward
+
+    def get_lr(self):
+        """actor_learner.py:115-119"""
+        if self.global_step <= self.lr_annealing_steps:
+            return self.initial_lr - (self.global_step * self.initial_lr / self.lr_annealing_steps)
+        return 0.0
+
+    def cleanup(self):
+        pass

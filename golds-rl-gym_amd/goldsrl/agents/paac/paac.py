@@ -1,0 +1,67 @@
+"""GridPAACLearner (reference fed_gym/agents/paac/paac.py:216-419) on the device engine.
+
+The while-loop body -- T x (predict, sample, transform, step, bookkeeping), bootstrap, n-step returns,
+train_step -- is two C calls (grl_net_rollout, grl_net_train_rollout); this class keeps the reference's
+constructor, counters, lr anneal and log line."""
+import logging
+import time
+
+from ... import _ffi
+from .actor_learner import ActorLearner
+
+
+class PAACLearner(ActorLearner):
+    def __init__(self, network_creator, environment_creator, args, emulator_class, state_processor):
+        super(PAACLearner, self).__init__(network_creator, environment_creator, args, emulator_class)
+        self.workers = args.emulator_workers
+        self.rnn_length = args.rnn_length
+        self.state_processor = state_processor
+
+    def train(self):
+        raise NotImplementedError("flat (Solow) PAAC training needs FlatPolicyVNetwork on the device: next round (DESIGN.md)")
+
+
+class GridPAACLearner(PAACLearner):
+    N_AGENTS = 10
+
+    def __init__(self, network_creator, environment_creator, args, emulator_class, state_processor):
+        super().__init__(network_creator, environment_creator, args, emulator_class, state_processor)
+        self.real_batch_size = self.emulator_counts * self.N_AGENTS
+        self.reward_layout = getattr(args, "reward_layout", "broadcast")    # 'reference' reproduces quirk Q4
+        self.engine = None
+
+    def rescale_reward(self, reward, lb=-2, ub=2):
+        return reward        # paac.py:223-224: Swarm rewards are not clipped
+
+    def train(self, max_updates=None):
+        device_id = 0
+        if isinstance(self.device, str) and ':' in self.device:
+            device_id = int(self.device.rsplit(':', 1)[1])
+        self.engine = _ffi.Engine(_ffi.ENV_SWARM, self.emulator_counts, device_id=device_id, grid_size=self.network.height,
+                                  seed=int(getattr(self, "seed", 1692)), max_episode_steps=128)
+        self.engine.reset()
+        self.network.bind(self.engine, gamma=self.gamma)
+        net = self.network.net
+        layout = 1 if self.reward_layout == 'reference' else 0
+        logging.debug("Starting training at Step {}".format(self.global_step))
+        counter, global_step_start, start_time = 0, self.global_step, time.time()
+        stats = None
+        while self.global_step < self.max_global_steps:
+            loop_start_time = time.time()
+            net.rollout(self.max_local_steps, layout)
+            self.global_step += self.max_local_steps * self.emulator_counts      # global_step += 1 per env per step (paac.py:341)
+            stats = net.train_rollout(self.get_lr())
+            counter += 1
+            if counter % max(1, int(5048 / self.emulator_counts)) == 0:
+                curr_time = time.time()
+                logging.info("Ran {} steps, at {} steps/s ({} steps/s avg), loss {}"
+                             .format(self.global_step,
+                                     self.max_local_steps * self.emulator_counts / (curr_time - loop_start_time),
+                                     (self.global_step - global_step_start) / (curr_time - start_time), stats["loss"]))
+            if max_updates is not None and counter >= max_updates:
+                break
+        return stats
+
+    def cleanup(self):
+        if self.network.net is not None:
+            self.network.net.close()

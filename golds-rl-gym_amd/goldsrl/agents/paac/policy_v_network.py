@@ -1,0 +1,43 @@
+"""Estimator objects with the reference's conf keys (fed_gym/agents/paac/policy_v_network.py,
+networks.py:100-167; conf built in scripts/train_paac_conv.py:67-83)."""
+from ... import _ffi_net
+
+
+class ConvSingleAgentPolicyNetwork(object):
+    """policy_v_network.py:5-80.  `bind(engine)` attaches the device net to a Swarm batch engine;
+    predict() then evaluates mu / sigma / vs for the engine's current observation."""
+
+    def __init__(self, conf):
+        self.conf = conf
+        self.name = conf.get('name', 'local_learning')
+        self.num_actions = conf['num_actions']
+        self.clip_norm = conf['clip_norm']
+        self.clip_norm_type = conf['clip_norm_type']
+        self.device = conf['device']
+        self.entropy_beta = conf['entropy_regularisation_strength']
+        self.scale = conf['scale']
+        self.height, self.width, self.channels = conf['height'], conf['width'], conf['channels']
+        self.fc_hidden = 256
+        if (self.height, self.width, self.channels, self.num_actions) != (84, 84, 3, 2):
+            raise ValueError("the device net is built for 84x84x3 inputs and 2 actions (train_paac_conv.py defaults)")
+        if self.clip_norm_type not in ('global', 'ignore'):
+            # 'local' is broken in the reference too (actor_learner.py:60-61 iterates (grad, var) tuples)
+            raise Exception('Norm type not recognized')
+        self.net = None
+
+    def bind(self, engine, gamma=0.99, seed=3, chunk=40960):
+        clip = self.clip_norm if self.clip_norm_type == 'global' else 0.0
+        self.net = _ffi_net.ConvNet(engine, max_chunk_samples=min(chunk, engine.E * 10), scale=self.scale,
+                                    entropy_beta=self.entropy_beta, clip_norm=clip, gamma=gamma)
+        self.net.set_params(_ffi_net.glorot_uniform_flat(seed))
+        return self
+
+    def predict(self, states=None, session=None):
+        """predict(states, session) in the reference; here the states are the bound engine's current ones."""
+        return self.net.predict()
+
+    def get_flat_params(self):
+        return self.net.get_params()
+
+    def set_flat_params(self, flat):
+        self.net.set_params(flat)

@@ -1,0 +1,76 @@
+"""SolowEnv / TradeAR1Env facades (reference fed_gym/envs/fed_env.py:161-334) over 1-env device engines."""
+import numpy as np
+
+from .. import _ffi
+
+registry = {}
+
+
+def register_solow_env(p, q):
+    """fed_env.py:10-27: three ids per (p, q)."""
+    registry["Solow-%s-%s-v0" % (p, q)] = (SolowEnv, None, dict(p=p, q=q))
+    registry["Solow-%s-%s-finite-v0" % (p, q)] = (SolowEnv, 1024, dict(p=p, q=q))
+    registry["Solow-%s-%s-finite-eval-v0" % (p, q)] = (SolowEnv, 1024, dict(p=p, q=q, seed=1692))
+
+
+class SolowEnv(object):
+    """Classic Solow model with ARMA(p,q) TFP shock and log-consumption reward (fed_env.py:161-250).
+    State is float32 on the device (BASELINE north_star), observations come back as float64 arrays."""
+
+    def __init__(self, delta=0.02, sigma=0.1, p=1, q=1, T=None, seed=None, max_episode_steps=None, device_id=0):
+        self.delta, self.sigma, self.alpha = delta, sigma, 0.33
+        self.seed_value = seed
+        self.T = T if T else 2048
+        self.p, self.q = p, q
+        flags = _ffi.F_RESEED_EACH_RESET if seed else 0
+        self._eng = _ffi.Engine(_ffi.ENV_SOLOW, 1, device_id=device_id, seed=int(seed if seed else 1692), flags=flags,
+                                solow_p=p, solow_q=q, solow_tape_len=self.T + (self.T & 1), solow_sigma=sigma, solow_delta=delta,
+                                max_episode_steps=int(max_episode_steps or 0))
+
+    def _k_ss(self, savings):
+        return (savings / self.delta) ** (1 / (1 - self.alpha))
+
+    def reset(self):
+        self._eng.reset()
+        return self._eng.read("obs_raw")[0].astype(np.float64)
+
+    def step(self, s):
+        self._eng.step(np.array([[float(np.asarray(s).reshape(-1)[0])]], np.float32))
+        obs = self._eng.read("obs_raw")[0].astype(np.float64)
+        return obs, float(self._eng.read("reward")[0]), bool(self._eng.read("done")[0]), {}
+
+    def seed(self, seed=None):
+        return []
+
+
+class TradeAR1Env(object):
+    """n-asset portfolio env with log-AR(1) prices (fed_env.py:268-334)."""
+
+    def __init__(self, starting_balance=10., base_rate=0.05, n_assets=2, std_p=0.05, max_episode_steps=None, device_id=0, seed=1692):
+        if starting_balance != 10.:
+            raise NotImplementedError("only the reference default starting_balance=10 is supported")
+        self.MIN_CASH = 1.
+        self.n_assets = n_assets
+        self.rho_p = 0.9
+        self.std_e = np.sqrt((std_p ** 2) * (1 - self.rho_p ** 2))
+        self._eng = _ffi.Engine(_ffi.ENV_TRADE, 1, device_id=device_id, seed=int(seed), n_assets=n_assets, trade_std_p=std_p,
+                                max_episode_steps=int(max_episode_steps or 0))
+
+    def reset(self):
+        self._eng.reset()
+        return self._eng.read("obs_raw")[0].astype(np.float64)
+
+    def step(self, action):
+        a = np.asarray(action, dtype=np.float32).reshape(1, self.n_assets)
+        self._eng.step_async(a)
+        try:
+            self._eng.wait()
+        except _ffi.GrlError as e:
+            if e.code == _ffi.E_ACTION_RANGE:
+                raise AssertionError("action outside Box(-1, 1)")      # `assert self.action_space.contains(action)`
+            raise
+        obs = self._eng.read("obs_raw")[0].astype(np.float64)
+        return obs, float(self._eng.read("reward")[0]), bool(self._eng.read("done")[0]), {}
+
+    def seed(self, seed=None):
+        return []

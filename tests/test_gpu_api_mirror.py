@@ -1,0 +1,171 @@
+"""The host-side mirror of the reference API (goldsrl.envs / agents.*), exercised the way the reference's
+own tests exercise fed_gym (tests/env_tests.py) and the way PAACLearner drives Runners (paac.py:86-137)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def test_swarm_env_like_reference_env_tests():
+    from goldsrl.envs import multiagent
+    env = multiagent.SwarmEnv()
+    env.reset()
+    rng = np.random.RandomState(0)
+    for _ in range(20):                              # tests/env_tests.py:10-25
+        state, reward, done, _ = env.step(rng.normal(size=(env.N_AGENTS, 2)))
+    assert len(state) == 2 and state[0].shape == (80, 2) and state[1].shape == (10, 2)
+    assert reward < 0. and not done
+
+
+def test_bounding_box_like_reference_env_tests():
+    from goldsrl.agents.state_processors import SwarmStateProcessor
+    from goldsrl.envs import multiagent
+    sp = SwarmStateProcessor()                      # grid_size=20 default, as in tests/env_tests.py:27-44
+    env = multiagent.SwarmEnv()
+    env.reset()
+    for _ in range(200):
+        state, reward, done, _ = env.step(np.zeros((10, 2)))
+    grid = sp.process_state(state)
+    assert grid.shape == (20, 20, 2) and abs(grid[:, :, 1].sum() - 1) < 1e-9
+    max_x, max_y = state[0].max(axis=0); min_x, min_y = state[0].min(axis=0)
+    mean_x = np.mean(state[0], axis=0)[0]
+    assert max_x < mean_x + 1.5 and min_x > mean_x - 1.5 and max_y < 6 and min_y >= 0
+    lb, ab, pos = O.swarm_observe_compact(state[0], state[1], 20)
+    assert np.array_equal(grid, O.swarm_grid_from_compact(lb, ab, 20)) and np.array_equal(sp.positions, pos)
+
+
+def test_make_applies_time_limit_and_eval_env_is_reseeded():
+    from goldsrl import envs
+    env = envs.make("Swarm-eval-v0")
+    s0 = [a.copy() for a in env.reset()]
+    for i in range(128):
+        s, r, d, _ = env.step(np.zeros((10, 2)))
+        assert d == (i == 127)                      # TimeLimit(128)
+    s1 = env.reset()
+    assert np.array_equal(s0[0], s1[0])             # seed=192 env repeats its episode
+    with pytest.raises(KeyError):
+        envs.make("Nope-v0")
+
+
+def test_trade_env_like_reference_env_tests():
+    from goldsrl.envs import fed_env
+    env = fed_env.TradeAR1Env(std_p=0.05)
+    env.reset()
+    for _ in range(100):                            # deplete_test (tests/env_tests.py:92-103)
+        state, reward, done, _ = env.step(np.array([0.1, 0.1]))
+    assert not done and state[0] <= env.MIN_CASH and (state[1:3] > 0).all()
+    env.reset()
+    env.step(np.array([0.1, 0.1]))
+    state, _, _, _ = env.step(np.array([-1., -1.]))  # buysell_test
+    np.testing.assert_array_almost_equal(0, state[1:3])
+    env.reset()
+    p = [env.step(np.array([0.0, 0.0]))[0][3:5] for _ in range(100)]     # prices_test
+    np.testing.assert_array_less(np.std(p, axis=0), 0.05 * 2)
+    with pytest.raises(AssertionError):
+        env.step(np.array([2.0, 0.0]))
+
+
+def test_solow_env_like_reference_env_tests():
+    from goldsrl.envs import fed_env
+    env = fed_env.SolowEnv(p=3, q=2)
+    env.reset()
+    for _ in range(100):                            # arima_test
+        state, consumption, done, _ = env.step(0.1)
+    assert not done
+    static = fed_env.SolowEnv(sigma=0.0, p=1, q=0, T=10000)     # SolowSSEnv's dynamics (fed_env.py:253-265)
+    static.reset()
+    for _ in range(10000):
+        state, _, done, _ = static.step(0.1)
+    np.testing.assert_allclose(state[0], (0.1 / 0.02) ** (1 / (1 - 0.33)), rtol=1e-5)
+
+
+def test_runners_drop_in_protocol_solow(golden):
+    """PAACLearner's use of Runners (paac.py:86-137): build variables from reset envs, write actions in
+    place, update_environments / wait_updated, read the shared arrays."""
+    from goldsrl.agents.paac.emulator_runner import SolowRunner
+    from goldsrl.agents.paac.environment_creator import SolowEnvironmentCreator
+    from goldsrl.agents.paac.runners import Runners
+    from goldsrl.agents.state_processors import SolowStateProcessor
+    E, rnn = 8, 5
+    creator = SolowEnvironmentCreator(1, 1)
+    emulators = np.asarray([creator.create_environment() for _ in range(E)])
+    sp = SolowStateProcessor()
+    initial_states = [sp.process_state(e.reset()) for e in emulators]
+    hist = np.zeros((E, rnn, 2), np.float32); hist[:, 0] = np.array(initial_states)
+    variables = [np.array(initial_states), hist, np.zeros(E, np.float32), np.zeros(E, np.float32), np.zeros((E, 1), np.float32)]
+
+    class Coord(object):
+        def should_stop(self): return False
+    runners = Runners(emulators, 4, variables, SolowRunner, Coord())
+    runners.start()
+    states, histories, rewards, overs, actions = runners.get_shared_variables()
+    k = states[:, 0].astype(np.float64) * 100; z = states[:, 1:2].astype(np.float64)
+    rng = np.random.RandomState(0)
+    tape = runners.engine.get_state("SOLOW_TAPE").astype(np.float64)
+    e = np.zeros((E, 1)); rho_z, rho_e = O.solow_rhos(1, 1)
+    for t in range(6):
+        a = SolowRunner.transform_actions_for_env(rng.normal(size=(E, 1)).astype(np.float32))
+        for i in range(E):
+            actions[i] = a[i]                      # in place, as paac.py:127-128
+        runners.update_environments(); runners.wait_updated()
+        k, z, e, obs, rew = O.solow_step(k, z, e, tape[:, 2047 - t], a[:, 0].astype(np.float64), rho_z, rho_e)
+        np.testing.assert_allclose(states, O.solow_process_state(obs), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(rewards, rew, rtol=1e-5, atol=5e-6)
+        assert not overs.any()
+        n = min(t + 1, rnn)
+        np.testing.assert_allclose(histories[:, :n], np.repeat(states[:, None], n, 1), rtol=1e-6)
+        assert (histories[:, n:] == 0).all()
+    with pytest.raises(ValueError):
+        Runners(emulators, 3, variables, SolowRunner, Coord())     # np.split: unequal division
+    runners.stop()
+
+
+def test_grid_runners_drop_in_protocol_swarm():
+    from goldsrl.agents.paac.emulator_runner import SwarmRunner
+    from goldsrl.agents.paac.environment_creator import SwarmEnvironmentCreator
+    from goldsrl.agents.paac.runners import GridRunners
+    from goldsrl.agents.state_processors import SwarmStateProcessor
+    E, G = 4, 84
+    creator = SwarmEnvironmentCreator()
+    assert creator.num_actions == 2
+    emulators = np.asarray([creator.create_environment() for _ in range(E)])
+    sp = SwarmStateProcessor(grid_size=G)
+    initial_states, idxs, raw = [], [], []
+    for em in emulators:                            # paac.py:245-251
+        s = em.reset(); raw.append(s)
+        g = sp.process_state(s)
+        initial_states.append(SwarmRunner.get_local_states(g, sp.positions)); idxs.append(sp.positions)
+    variables = [np.array(initial_states), None, np.array(idxs), np.zeros((E, 10), np.float32), np.zeros((E, 10), np.float32),
+                 np.zeros((E, 10, 2), np.float32)]
+    runners = GridRunners(emulators, 2, variables, SwarmRunner, None, G)
+    states, _, positions, rewards, overs, actions = runners.get_shared_variables()
+    rng = np.random.RandomState(3)
+    a = SwarmRunner.transform_actions_for_env(rng.normal(size=(E * 10, 2)).astype(np.float32)).reshape(E, 10, 2)
+    for i in range(E):
+        actions[i] = a[i]
+    runners.update_environments(); runners.wait_updated()
+    x = np.stack([r[0] for r in raw]); xa = np.stack([r[1] for r in raw])
+    ox, oxa, orew, _ = O.swarm_step(x, xa, a.astype(np.float64), runners.engine.get_state("SWARM_ANOISE") * 0 + np.stack(
+        [em._eng.get_state("SWARM_ANOISE")[0] for em in emulators]), np.stack([em._eng.get_state("SWARM_PNOISE")[0] for em in emulators]))
+    np.testing.assert_allclose(rewards, np.repeat(orew[:, None], 10, 1), rtol=1e-6)
+    for i in range(E):
+        lb, ab, pos = O.swarm_observe_compact(ox[i], oxa[i], G)
+        assert np.array_equal(positions[i], pos)
+        np.testing.assert_array_equal(states[i], O.swarm_local_states(O.swarm_grid_from_compact(lb, ab, G), pos).astype(np.float32))
+    assert not overs.any()
+
+
+def test_grid_paac_learner_runs_updates():
+    from goldsrl.scripts import train_paac_conv as S
+    args = S.get_arg_parser().parse_args(["-ec", "64", "--max_local_steps", "5", "--max_global_steps", "640"])
+    nc, ec = S.get_network_and_environment_creator(args)
+    from goldsrl.agents.paac.emulator_runner import SwarmRunner
+    from goldsrl.agents.paac.paac import GridPAACLearner
+    learner = GridPAACLearner(nc, ec, args, SwarmRunner, state_processor=None)
+    assert learner.get_lr() == 1e-4
+    stats = learner.train()
+    assert learner.global_step == 640 and np.isfinite(stats["loss"])
+    assert learner.get_lr() == 1e-4 - 640 * 1e-4 / 80000000
+    assert learner.rescale_reward(-5.0) == -5.0
