@@ -95,6 +95,13 @@ def cpu_baseline(sample_envs, T):
     OC.swarm_step(x[:64], xa[:64], act[:64], an[:64], pn[:64], threads=1)
     out = {}
     ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:   # the GPU box grants a CPU share through the cgroup, not through affinity
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            ncores = max(1, min(ncores, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    ncores = min(ncores, 32)
     for label, threads in (("1core", 1), ("allcores", ncores)):
         xx, xxa = x.copy(), xa.copy()
         t0 = time.perf_counter()

@@ -1,0 +1,70 @@
+/* goldsrl_flatnet.h -- C ABI of FlatPolicyVNetwork (GRU + MLP) on the device.
+ *
+ * Replaces (paths relative to the reference repo root):
+ *   fed_gym/agents/paac/policy_v_network.py:194-264   FlatPolicyVNetwork (+ predict())
+ *   fed_gym/agents/a3c/estimators.py:5-28             make_cell / true_length / rnn_graph_lstm (GRU trunk)
+ *   fed_gym/agents/paac/paac.py:23-38,119-187         choose_next_actions, PAACLearner.train inner loop
+ *   fed_gym/agents/paac/actor_learner.py:31-68,91-97  Adam, clip_by_global_norm, reward clip
+ * Flat parameter vector, tf.trainable_variables() creation order (D = temporal_size, S0 = static_size,
+ * H = rnn hidden = 32, S = static hidden = 32, A = num_actions):
+ *   gru_gates_w[D+H,2H] gru_gates_b[2H] gru_cand_w[D+H,H] gru_cand_b[H] temporal_w[H,2H] temporal_b
+ *   static1_w[S0,2H] static1_b static2_w[2H,H] static2_b mu1_w[3H,2S] mu1_b mu2_w[2S,S] mu2_b mu3_w[S,A] mu3_b
+ *   sig1_w sig1_b sig2_w sig2_b sig3_w sig3_b v1_w[3H,2S] v1_b v2_w[2S,1] v2_b
+ * Conventions as in goldsrl.h.
+ */
+#ifndef GOLDSRL_FLATNET_H
+#define GOLDSRL_FLATNET_H
+
+#include "goldsrl.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct grl_fnet_config {
+    int32_t struct_size;
+    int32_t static_size;    /* conf['static_size']   (--static-size, 2; TradeAR1: 1+2n) */
+    int32_t temporal_size;  /* conf['temporal_size'] (--temporal-size, 2) */
+    int32_t rnn_length;     /* history rows fed to the GRU (--rnn-length, 5); <= 32 */
+    int32_t num_actions;    /* 1 for Solow; <= 16 */
+    int32_t rnn_hidden;     /* conf['rnn_hidden_size'], must be 32 (--temporal-hidden-size default) */
+    int32_t static_hidden;  /* conf['static_hidden_size'], must be 32 */
+    int32_t max_samples;    /* largest n of one predict/train call (workspace size) */
+    float scale;            /* conf['scale'] (train_paac_solow.py --scale, 100) */
+    float clip_norm;        /* 40, 'global'; <= 0: 'ignore' */
+    float gamma;            /* 0.99 */
+    float mu_bound;         /* ub = -lb = 5 (policy_v_network.py:207-208) */
+} grl_fnet_config;
+
+typedef struct grl_fnet grl_fnet;
+
+int grl_fnet_config_default(grl_fnet_config *cfg);
+int grl_fnet_create(grl_handle *h, const grl_fnet_config *cfg, grl_fnet **out);
+int grl_fnet_destroy(grl_fnet *net);
+const char *grl_fnet_last_error(const grl_fnet *net);
+int64_t grl_fnet_num_params(const grl_fnet *net);
+int grl_fnet_set_params(grl_fnet *net, const float *host, int64_t n);
+int grl_fnet_get_params(grl_fnet *net, float *host, int64_t n);
+int grl_fnet_get_grads(grl_fnet *net, float *host, int64_t n);
+
+/* network.predict(states, histories) + the value head, on HOST arrays: states (n,S0), history (n,T,D),
+ * outputs mu (n,A) sigma (n,A) vs (n,) (any may be NULL).  Synchronous. */
+int grl_fnet_predict(grl_fnet *net, int32_t n, const float *states, const float *history, float *mu, float *sigma, float *vs);
+/* Same on the CURRENT observation/history of the (Solow) handle the net was created on: n = num_envs. */
+int grl_fnet_predict_env(grl_fnet *net, float *mu, float *sigma, float *vs);
+/* One gradient step on HOST samples: loss of policy_v_network.py:228-251 (no entropy term), backward through
+ * the length-masked GRU, clip_by_global_norm, Adam.  advantages are ALREADY divided by scale (paac.py:177).
+ * stats_host: {loss, policy_loss, critic_loss_mean, global_norm}.  apply_update=0: gradients only. */
+int grl_fnet_train(grl_fnet *net, int32_t n, const float *states, const float *history, const float *actions,
+                   const float *advantages, const float *critic_target, float lr, int32_t apply_update, float *stats_host);
+/* Device-resident PAAC rollout on the Solow handle (paac.py:119-172): T x [forward, a = mu + sigma*N(0,1),
+ * sigmoid, env step/auto-reset/observe/history], bootstrap, reward clip +-2, MASKED n-step returns. Async. */
+int grl_fnet_rollout(grl_fnet *net, int32_t T);
+int grl_fnet_train_rollout(grl_fnet *net, float lr, float *stats_host);
+/* "actions" (T,E,A) "values" (T,E) "rewards" (T,E) raw "masks" (T,E) "y" (T,E) "adv" (T,E) "boot" (E,) */
+int grl_fnet_read_rollout(grl_fnet *net, const char *which, void *host, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GOLDSRL_FLATNET_H */

@@ -274,6 +274,73 @@ def flat_loss(p, states, history, actions, advantages, critic_target, scale):
     return loss, pl, cl
 
 
+def flat_loss_and_grads(p, states, history, actions, advantages, critic_target, scale, ub=5.0, lb=-5.0):
+    """Analytic gradients of FlatPolicyVNetwork's loss (policy_v_network.py:228-251) incl. back-propagation
+    through the length-masked GRU.  Returns loss, policy_loss, critic_loss_mean, grads, (mu, sigma, vs)."""
+    N, T, D = history.shape
+    H = p["gru_cand_b"].shape[0]
+    length = np.sign(np.max(np.abs(history), axis=2)).sum(axis=1).astype(int)
+    hs, rs, us, cs = [np.zeros((N, H))], [], [], []
+    h = hs[0]
+    for t in range(T):
+        x = history[:, t]
+        gates = _sigmoid(np.concatenate([x, h], 1) @ p["gru_gates_w"] + p["gru_gates_b"])
+        r, u = gates[:, :H], gates[:, H:]
+        c = np.tanh(np.concatenate([x, r * h], 1) @ p["gru_cand_w"] + p["gru_cand_b"])
+        h = np.where((t < length)[:, None], u * h + (1 - u) * c, h)
+        rs.append(r); us.append(u); cs.append(c); hs.append(h)
+    dt_ = np.maximum(h @ p["temporal_w"] + p["temporal_b"], 0)
+    s1 = np.maximum(states @ p["static1_w"] + p["static1_b"], 0)
+    s2 = np.maximum(s1 @ p["static2_w"] + p["static2_b"], 0)
+    x96 = np.concatenate([dt_, s2], axis=1)
+    m1 = np.maximum(x96 @ p["mu1_w"] + p["mu1_b"], 0); m2 = np.tanh(m1 @ p["mu2_w"] + p["mu2_b"])
+    tm = np.tanh(m2 @ p["mu3_w"] + p["mu3_b"]); mu = ((ub - lb) / 2.0) * tm + (lb + ub) / 2.0
+    g1 = np.maximum(x96 @ p["sig1_w"] + p["sig1_b"], 0); g2 = np.tanh(g1 @ p["sig2_w"] + p["sig2_b"])
+    sg = _sigmoid(g2 @ p["sig3_w"] + p["sig3_b"]); sigma = sg + 1e-3
+    v1 = np.tanh(x96 @ p["v1_w"] + p["v1_b"]); vs = scale * (v1 @ p["v2_w"] + p["v2_b"])[:, 0]
+    loss, pl, cl, dmu, dsigma, dvs = gaussian_loss_terms(mu, sigma, actions, advantages, critic_target, vs, 0.0, scale,
+                                                         entropy_in_loss=False)
+    g = {}
+
+    def dense_bwd(name, x, dz):
+        g[name + "_w"], g[name + "_b"] = x.T @ dz, dz.sum(0)
+        return dz @ p[name + "_w"].T
+    dz = dmu * ((ub - lb) / 2.0) * (1 - tm ** 2)
+    dm2 = dense_bwd("mu3", m2, dz) * (1 - m2 ** 2)
+    dm1 = dense_bwd("mu2", m1, dm2) * (m1 > 0)
+    dx = dense_bwd("mu1", x96, dm1)
+    dz = dsigma * sg * (1 - sg)
+    dg2 = dense_bwd("sig3", g2, dz) * (1 - g2 ** 2)
+    dg1 = dense_bwd("sig2", g1, dg2) * (g1 > 0)
+    dx = dx + dense_bwd("sig1", x96, dg1)
+    dzv = (dvs * scale)[:, None]
+    dv1 = dense_bwd("v2", v1, dzv) * (1 - v1 ** 2)
+    dx = dx + dense_bwd("v1", x96, dv1)
+    ddt, ds2 = dx[:, :2 * H] * (dt_ > 0), dx[:, 2 * H:] * (s2 > 0)
+    ds1 = dense_bwd("static2", s1, ds2) * (s1 > 0)
+    dense_bwd("static1", states, ds1)
+    dh = dense_bwd("temporal", h, ddt)
+    g["gru_gates_w"] = np.zeros_like(p["gru_gates_w"]); g["gru_gates_b"] = np.zeros_like(p["gru_gates_b"])
+    g["gru_cand_w"] = np.zeros_like(p["gru_cand_w"]); g["gru_cand_b"] = np.zeros_like(p["gru_cand_b"])
+    for t in reversed(range(T)):
+        act = (t < length)[:, None]
+        hp, r, u, c = hs[t], rs[t], us[t], cs[t]
+        x = history[:, t]
+        dhn = np.where(act, dh, 0.0)
+        du, dc, dh_keep = dhn * (hp - c), dhn * (1 - u), dhn * u
+        dzc = dc * (1 - c ** 2)
+        xin = np.concatenate([x, r * hp], 1)
+        g["gru_cand_w"] += xin.T @ dzc; g["gru_cand_b"] += dzc.sum(0)
+        drh = (dzc @ p["gru_cand_w"].T)[:, D:]
+        dr = drh * hp
+        dzg = np.concatenate([dr * r * (1 - r), du * u * (1 - u)], 1)
+        xin = np.concatenate([x, hp], 1)
+        g["gru_gates_w"] += xin.T @ dzg; g["gru_gates_b"] += dzg.sum(0)
+        dh_prev = dh_keep + drh * r + (dzg @ p["gru_gates_w"].T)[:, D:]
+        dh = np.where(act, dh_prev, dh)
+    return loss, pl, cl, g, (mu, sigma, vs)
+
+
 def numeric_grad(f, p, names, eps=1e-6, max_per=6, seed=0):
     """Central finite differences on a few random entries of each named parameter."""
     rng = np.random.RandomState(seed)

@@ -1,0 +1,115 @@
+"""GPU parity of FlatPolicyVNetwork (GRU + MLP, HIP, one lane per sample) against oracle/nets.py (float64,
+'parity unpinned' wrt TensorFlow) with shared weights; and the flat PAAC rollout on the Solow engine."""
+import numpy as np
+import pytest
+
+from oracle import nets as NN
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _net(kind_kw, n_env=8, **cfg):
+    from goldsrl import _ffi, _ffi_flat
+    eng = _ffi.Engine(_ffi.ENV_SOLOW, n_env, seed=5, **kind_kw)
+    eng.reset()
+    net = _ffi_flat.FlatNet(eng, **cfg)
+    return eng, net
+
+
+def _params(net, static_size=2, temporal_size=2, num_actions=1, seed=4):
+    from goldsrl import _ffi_flat
+    shapes = _ffi_flat.flat_param_shapes(static_size, temporal_size, num_actions)
+    assert [tuple(s) for _, s in shapes] == [tuple(s) for _, s in NN.flat_param_shapes(static_size, temporal_size, 32, 32, num_actions)]
+    flat = _ffi_flat.default_init_flat(seed, static_size=static_size, temporal_size=temporal_size, num_actions=num_actions)
+    rng = np.random.RandomState(seed)
+    flat = flat + (rng.normal(size=flat.size) * 0.05).astype(np.float32)      # move biases off their init
+    net.set_params(flat)
+    assert net.num_params == flat.size
+    return NN.unflatten_params(flat.astype(np.float64), NN.flat_param_shapes(static_size, temporal_size, 32, 32, num_actions))
+
+
+def _samples(n, S0, D, T, A, seed=0):
+    rng = np.random.RandomState(seed)
+    states = (rng.normal(size=(n, S0)) * 0.3).astype(np.float32)
+    hist = (rng.normal(size=(n, T, D)) * 0.3).astype(np.float32)
+    for i in range(n):
+        hist[i, 1 + i % T:] = 0          # ragged lengths 1..T (zero rows end the sequence)
+    act = rng.normal(size=(n, A)).astype(np.float32) * 2
+    adv = (rng.normal(size=n) * 0.3).astype(np.float32)
+    y = (rng.normal(size=n) * 40).astype(np.float32)
+    return states, hist, act, adv, y
+
+
+@pytest.mark.parametrize("S0,D,T,A", [(2, 2, 5, 1), (33, 33, 20, 16)])     # Solow defaults; TradeAR1-16 shapes (train_trade.py:38-40,119)
+def test_flat_forward_and_gradients_match_oracle(S0, D, T, A):
+    n = 150       # three wave-groups, last one partial
+    eng, net = _net({}, static_size=S0, temporal_size=D, rnn_length=T, num_actions=A, max_samples=256, scale=100.0)
+    p = _params(net, S0, D, A)
+    states, hist, act, adv, y = _samples(n, S0, D, T, A)
+    out = net.predict(states, hist)
+    mu, sigma, vs = NN.flat_forward(p, states.astype(np.float64), hist.astype(np.float64), 100.0)
+    np.testing.assert_allclose(out["mu"], mu, rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(out["sigma"], sigma, rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(out["vs"], vs, rtol=2e-5, atol=2e-4)
+    assert (np.abs(out["mu"]) <= 5).all() and (out["sigma"] > 1e-3).all()
+    st = net.train(states, hist, act, adv, y, lr=0.0, apply_update=False)
+    loss, pl, cl, g, _ = NN.flat_loss_and_grads(p, states.astype(np.float64), hist.astype(np.float64), act.astype(np.float64),
+                                                adv.astype(np.float64), y.astype(np.float64), 100.0)
+    np.testing.assert_allclose([st["loss"], st["policy_loss"], st["critic_loss_mean"]], [loss, pl, cl], rtol=1e-4, atol=1e-6)
+    shapes = NN.flat_param_shapes(S0, D, 32, 32, A)
+    got = NN.unflatten_params(net.get_grads().astype(np.float64), shapes)
+    for name, _ in shapes:
+        err = np.abs(got[name] - g[name]).max() / (np.abs(g[name]).max() + 1e-12)
+        assert err < 2e-4, (name, err)
+    np.testing.assert_allclose(st["global_norm"], np.sqrt(sum((v ** 2).sum() for v in g.values())), rtol=1e-4)
+    first = net.get_grads()
+    net.train(states, hist, act, adv, y, lr=0.0, apply_update=False)
+    assert np.array_equal(first, net.get_grads())          # fixed-order reduction: reproducible
+
+
+def test_flat_adam_steps_match_oracle():
+    eng, net = _net({}, max_samples=256, clip_norm=0.05)
+    p = _params(net)
+    shapes = NN.flat_param_shapes()
+    states, hist, act, adv, y = _samples(100, 2, 2, 5, 1, seed=3)
+    pf = NN.flatten_params(p, shapes); flat0 = pf.copy(); m = np.zeros_like(pf); v = np.zeros_like(pf)
+    for step in range(1, 4):
+        _, _, _, g, _ = NN.flat_loss_and_grads(NN.unflatten_params(pf, shapes), states.astype(np.float64), hist.astype(np.float64),
+                                               act.astype(np.float64), adv.astype(np.float64), y.astype(np.float64), 100.0)
+        gf, norm = NN.clip_by_global_norm(NN.flatten_params(g, shapes), 0.05)
+        assert norm > 0.05
+        pf, m, v = NN.adam_step(pf, gf, m, v, step, 1e-3)
+        st = net.train(states, hist, act, adv, y, lr=1e-3)
+        np.testing.assert_allclose(st["global_norm"], norm, rtol=2e-4)
+        np.testing.assert_allclose(net.get_params().astype(np.float64) - flat0, pf - flat0, rtol=0, atol=3e-5 * step)
+
+
+def test_flat_paac_rollout_on_solow_engine():
+    E, T = 256, 20
+    eng, net = _net({"max_episode_steps": 8}, n_env=E, max_samples=E * T)
+    p = _params(net)
+    obs0, hist0 = eng.read("obs"), eng.read("history")
+    pred = net.predict_env()
+    mu, sigma, vs = NN.flat_forward(p, obs0.astype(np.float64), hist0.astype(np.float64), 100.0)
+    np.testing.assert_allclose(pred["vs"], vs, rtol=2e-5, atol=2e-4)
+    net.rollout(T)
+    eng.wait()
+    acts, vals, rews, masks = (net.read_rollout(k, (T, E)) for k in ("actions", "values", "rewards", "masks"))
+    yy, adv, boot = net.read_rollout("y", (T, E)), net.read_rollout("adv", (T, E)), net.read_rollout("boot", (E,))
+    assert np.array_equal(vals[0], pred["vs"])
+    eps = O.normal_pair(O.rng_block(5, np.arange(E), 0, 17, 0))[0]
+    np.testing.assert_allclose(acts[0], pred["mu"][:, 0].astype(np.float64) + pred["sigma"][:, 0].astype(np.float64) * eps, rtol=1e-6, atol=1e-6)
+    # TimeLimit(8): every env finishes at steps 7 and 15 -> masks are 0 there and the return restarts
+    assert (masks[7] == 0).all() and (masks[15] == 0).all() and masks.sum() == (T - 2) * E
+    oy, oadv = O.nstep_returns(O.rescale_reward(rews).astype(np.float64), vals, boot, 0.99, masks.astype(np.float64))
+    np.testing.assert_allclose(yy, oy, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(adv, oadv / 100.0, rtol=1e-5, atol=1e-6)
+    # stored (state, history) pairs reproduce the stored values through predict()
+    st_ = net.read_rollout("states", (T, E, 2)); hi_ = net.read_rollout("histories", (T, E, 5, 2))
+    np.testing.assert_array_equal(net.predict(st_[9], hi_[9])["vs"], vals[9])
+    stats = net.train_rollout(1e-4)
+    assert all(np.isfinite(list(stats.values()))) and stats["global_norm"] > 0
+    # one more rollout with the updated weights still runs (values change)
+    net.rollout(T); eng.wait()
+    assert not np.array_equal(net.read_rollout("values", (T, E)), vals)

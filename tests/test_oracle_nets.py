@@ -71,3 +71,26 @@ def test_gru_sequence_length_masking():
     assert np.allclose(h[1], h_short[0])
     mu, sigma, vs = NN.flat_forward(p, rng.normal(size=(4, 2)), hist, 100.0)
     assert (np.abs(mu) <= 5).all() and (sigma > 1e-3).all() and mu.shape == (4, 1)
+
+
+def test_flat_gradients_match_finite_differences():
+    p = NN.flat_init(seed=4)
+    rng = np.random.RandomState(2)
+    for k in p:
+        if k.endswith("_b"):
+            p[k] = p[k] + rng.normal(size=p[k].shape) * 0.1
+    n = 6
+    states = rng.normal(size=(n, 2)) * [0.3, 0.1] + [0.65, 0.0]
+    hist = np.repeat(states[:, None], 5, 1)
+    for i, L in enumerate((1, 2, 3, 5, 5, 4)):
+        hist[i, L:] = 0                                   # quirk Q11 windows of different lengths
+    act, adv, y = rng.normal(size=(n, 1)), rng.normal(size=n) * 0.5, rng.normal(size=n) * 50
+    loss, pl, cl, g, (mu, sigma, vs) = NN.flat_loss_and_grads(p, states, hist, act, adv, y, 100.0)
+    l2, pl2, cl2 = NN.flat_loss(p, states, hist, act, adv, y, 100.0)
+    assert abs(loss - l2) < 1e-12
+    shapes = NN.flat_param_shapes()
+    f = lambda q: NN.flat_loss(q, states, hist, act, adv, y, 100.0)[0]
+    num = NN.numeric_grad(f, p, [nm for nm, _ in shapes], eps=1e-6, max_per=4)
+    for nm, vals in num.items():
+        for idx, gv in vals:
+            assert abs(g[nm][idx] - gv) <= 2e-3 * abs(gv) + 1e-6, (nm, idx, g[nm][idx], gv)
