@@ -5,6 +5,7 @@ from ... import envs
 class SolowEnvironmentCreator(object):
     def __init__(self, p, q):
         self.num_actions = 1
+        self.p, self.q = p, q
         envs.register_solow_env(p, q)
         self.create_environment = lambda: envs.make("Solow-%s-%s-finite-v0" % (p, q))
 

@@ -17,8 +17,35 @@ class PAACLearner(ActorLearner):
         self.rnn_length = args.rnn_length
         self.state_processor = state_processor
 
-    def train(self):
-        raise NotImplementedError("flat (Solow) PAAC training needs FlatPolicyVNetwork on the device: next round (DESIGN.md)")
+    def train(self, max_updates=None):
+        """PAACLearner.train (paac.py:55-209) for SolowRunner: masked returns, rewards clipped to +-2."""
+        device_id = 0
+        if isinstance(self.device, str) and ':' in self.device:
+            device_id = int(self.device.rsplit(':', 1)[1])
+        p, q = getattr(self.environment_creator, "p", 1), getattr(self.environment_creator, "q", 1)
+        self.engine = _ffi.Engine(_ffi.ENV_SOLOW, self.emulator_counts, device_id=device_id, solow_p=p, solow_q=q,
+                                  rnn_length=self.rnn_length, max_episode_steps=1024, seed=int(getattr(self, "seed", 1692)))
+        self.engine.reset()
+        self.network.bind(self.engine, rnn_length=self.rnn_length, gamma=self.gamma,
+                          max_samples=self.emulator_counts * self.max_local_steps)
+        net = self.network.net
+        counter, global_step_start, start_time = 0, self.global_step, time.time()
+        stats = None
+        while self.global_step < self.max_global_steps:
+            loop_start_time = time.time()
+            net.rollout(self.max_local_steps)
+            self.global_step += self.max_local_steps * self.emulator_counts      # paac.py:149
+            stats = net.train_rollout(self.get_lr())
+            counter += 1
+            if counter % max(1, int(5048 / self.emulator_counts)) == 0:
+                curr_time = time.time()
+                logging.info("Ran {} steps, at {} steps/s ({} steps/s avg), loss {}"
+                             .format(self.global_step,
+                                     self.max_local_steps * self.emulator_counts / (curr_time - loop_start_time),
+                                     (self.global_step - global_step_start) / (curr_time - start_time), stats["loss"]))
+            if max_updates is not None and counter >= max_updates:
+                break
+        return stats
 
 
 class GridPAACLearner(PAACLearner):

@@ -1,6 +1,6 @@
 """Estimator objects with the reference's conf keys (fed_gym/agents/paac/policy_v_network.py,
 networks.py:100-167; conf built in scripts/train_paac_conv.py:67-83)."""
-from ... import _ffi_net
+from ... import _ffi_flat, _ffi_net
 
 
 class ConvSingleAgentPolicyNetwork(object):
@@ -41,3 +41,37 @@ class ConvSingleAgentPolicyNetwork(object):
 
     def set_flat_params(self, flat):
         self.net.set_params(flat)
+
+
+class FlatPolicyVNetwork(object):
+    """policy_v_network.py:194-264 (GRU(32) over the history window + static MLP, three heads)."""
+
+    def __init__(self, conf):
+        self.conf = conf
+        self.name = conf.get('name', 'local_learning')
+        self.num_actions = conf['num_actions']
+        self.clip_norm = conf['clip_norm']
+        self.clip_norm_type = conf['clip_norm_type']
+        self.device = conf['device']
+        self.scale = conf['scale']
+        self.static_size = conf['static_size']
+        self.temporal_size = conf['temporal_size']
+        self.entropy_regularisation_strength = conf['entropy_regularisation_strength']    # unused by the loss (:230-235)
+        if conf['static_hidden_size'] != 32 or conf['rnn_hidden_size'] != 32:
+            raise ValueError("the device net is built for the reference's default hidden sizes (32)")
+        if self.clip_norm_type not in ('global', 'ignore'):
+            raise Exception('Norm type not recognized')
+        self.net = None
+
+    def bind(self, engine, rnn_length=5, gamma=0.99, seed=3, max_samples=None):
+        clip = self.clip_norm if self.clip_norm_type == 'global' else 0.0
+        self.net = _ffi_flat.FlatNet(engine, static_size=self.static_size, temporal_size=self.temporal_size, rnn_length=rnn_length,
+                                     num_actions=self.num_actions, scale=self.scale, clip_norm=clip, gamma=gamma,
+                                     max_samples=max_samples or engine.E * 64)
+        self.net.set_params(_ffi_flat.default_init_flat(seed, static_size=self.static_size, temporal_size=self.temporal_size,
+                                                        num_actions=self.num_actions))
+        return self
+
+    def predict(self, states, histories, session=None):
+        out = self.net.predict(states, histories)
+        return {'mu': out['mu'], 'sigma': out['sigma']}          # the reference's predict returns only these two (:253-264)

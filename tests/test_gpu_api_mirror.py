@@ -169,3 +169,19 @@ def test_grid_paac_learner_runs_updates():
     assert learner.global_step == 640 and np.isfinite(stats["loss"])
     assert learner.get_lr() == 1e-4 - 640 * 1e-4 / 80000000
     assert learner.rescale_reward(-5.0) == -5.0
+
+
+def test_flat_paac_learner_runs_updates():
+    from goldsrl.agents.paac.emulator_runner import SolowRunner
+    from goldsrl.agents.paac.paac import PAACLearner
+    from goldsrl.agents.state_processors import SolowStateProcessor
+    from goldsrl.scripts import train_paac_solow as S
+    args = S.get_arg_parser().parse_args(["-ec", "128", "--max_local_steps", "20", "--max_global_steps", "7680"])
+    assert args.scale == 100.0 and args.rnn_length == 5
+    nc, ec = S.get_network_and_environment_creator(args)
+    learner = PAACLearner(nc, ec, args, SolowRunner, SolowStateProcessor())
+    stats = learner.train()
+    assert learner.global_step == 7680 and np.isfinite(stats["loss"])
+    assert learner.rescale_reward(-5.0) == -2 and learner.rescale_reward(0.3) == 0.3      # actor_learner.py:91-97
+    out = learner.network.predict(np.array([[0.65, 0.0]], np.float32), np.zeros((1, 5, 2), np.float32))
+    assert set(out) == {"mu", "sigma"}
