@@ -47,6 +47,7 @@ struct grl_net {
     std::string err;
     int chunk;                 // samples per pass
     float *params, *grads, *adam_m, *adam_v;
+    float *paramsT;            // W^T of every GEMM layer at the same flat offsets ([N][K]: the forward's Bt operand)
     long adam_t;
     // forward activations (chunk)
     float *a1, *a2, *a3, *d1, *d2, *p1, *v1, *v2;
@@ -110,6 +111,27 @@ struct GemmTimer {
         }
     }
 };
+
+// dst[n][k] = src[k][n]
+__global__ void transpose_kernel(const float *__restrict__ src, int K, int N, float *__restrict__ dst) {
+    __shared__ float tile[32][33];
+    int k0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    for (int r = threadIdx.y; r < 32; r += blockDim.y)
+        if (k0 + r < K && n0 + (int)threadIdx.x < N) tile[r][threadIdx.x] = src[(long)(k0 + r) * N + n0 + threadIdx.x];
+    __syncthreads();
+    for (int r = threadIdx.y; r < 32; r += blockDim.y)
+        if (n0 + r < N && k0 + (int)threadIdx.x < K) dst[(long)(n0 + r) * K + k0 + threadIdx.x] = tile[threadIdx.x][r];
+}
+
+// keep paramsT in step with params (after set_params, Adam, broadcast)
+static void refresh_transposes(grl_net *net) {
+    static const struct { long off; int K, N; } L[] = {
+        {ConvOffsets::c2w, 512, 64}, {ConvOffsets::c3w, 576, 64}, {ConvOffsets::d1w, 3136, 512}, {ConvOffsets::d2w, 512, 256},
+        {ConvOffsets::p1w, 256, 512}, {ConvOffsets::v1w, 256, 512}, {ConvOffsets::v2w, 512, 256}};
+    for (const auto &l : L)
+        hipLaunchKernelGGL(transpose_kernel, dim3((l.N + 31) / 32, (l.K + 31) / 32), dim3(32, 8), 0, net->h->stream, net->params + l.off,
+                           l.K, l.N, net->paramsT + l.off);
+}
 
 // ------------------------------------------------------------------------------------------ conv1 (sparse)
 // One workgroup per env.  Axis convention of the reference image: states[n][h][w][c] with h = x-bin,
@@ -230,7 +252,7 @@ __global__ void sample_actions_kernel(const float *__restrict__ mu, const float 
 static int forward_chunk(grl_net *net, const uint8_t *lb, const uint8_t *ab, const uint8_t *pos, int nenv, float *mu,
                          float *sigma, float *vs) {
     hipStream_t st = net->h->stream;
-    const float *P = net->params;
+    const float *P = net->params, *PT = net->paramsT;
     const int n = nenv * 10;
     net->last_n = n;
     hipLaunchKernelGGL(conv1_sparse_kernel, dim3(nenv), dim3(256), 0, st, lb, ab, pos, P + ConvOffsets::c1w, P + ConvOffsets::c1b,
@@ -239,28 +261,28 @@ static int forward_chunk(grl_net *net, const uint8_t *lb, const uint8_t *ab, con
         GatherConv2 g{net->a1, n * 81};
         EpiBiasAct e{net->a2, 64, P + ConvOffsets::c2b, ACT_RELU};
         GemmTimer t(net, 2.0 * n * 81 * 512 * 64);
-        hipLaunchKernelGGL((gemm_rowk<256, 64, 4, 1, false, GatherConv2, EpiBiasAct>), dim3((n * 81 + 255) / 256, 1), dim3(256), 0, st,
-                           g, P + ConvOffsets::c2w, 64, 64, e);
+        hipLaunchKernelGGL((gemm_rowk<256, 64, 4, 1, GatherConv2, EpiBiasAct>), dim3((n * 81 + 255) / 256, 1), dim3(256), 0, st,
+                           g, PT + ConvOffsets::c2w, 512, 64, e);
     }
     {
         GatherConv3 g{net->a2, n * 49};
         EpiBiasAct e{net->a3, 64, P + ConvOffsets::c3b, ACT_RELU};
         GemmTimer t(net, 2.0 * n * 49 * 576 * 64);
-        hipLaunchKernelGGL((gemm_rowk<256, 64, 4, 1, false, GatherConv3, EpiBiasAct>), dim3((n * 49 + 255) / 256, 1), dim3(256), 0, st,
-                           g, P + ConvOffsets::c3w, 64, 64, e);
+        hipLaunchKernelGGL((gemm_rowk<256, 64, 4, 1, GatherConv3, EpiBiasAct>), dim3((n * 49 + 255) / 256, 1), dim3(256), 0, st,
+                           g, PT + ConvOffsets::c3w, 576, 64, e);
     }
     auto dense = [&](const float *in, int K, const float *w, const float *b, int N, float *out) {
         DenseRows g{in, n, K, K};
         EpiBiasAct e{out, N, b, ACT_RELU};
         GemmTimer t(net, 2.0 * n * K * N);
-        hipLaunchKernelGGL((gemm_rowk<128, 128, 2, 2, false, DenseRows, EpiBiasAct>), dim3((n + 127) / 128, N / 128), dim3(256), 0, st, g,
-                           w, N, N, e);
+        hipLaunchKernelGGL((gemm_rowk<128, 128, 2, 2, DenseRows, EpiBiasAct>), dim3((n + 127) / 128, N / 128), dim3(256), 0, st, g,
+                           w, K, N, e);
     };
-    dense(net->a3, 3136, P + ConvOffsets::d1w, P + ConvOffsets::d1b, 512, net->d1);
-    dense(net->d1, 512, P + ConvOffsets::d2w, P + ConvOffsets::d2b, 256, net->d2);
-    dense(net->d2, 256, P + ConvOffsets::p1w, P + ConvOffsets::p1b, 512, net->p1);
-    dense(net->d2, 256, P + ConvOffsets::v1w, P + ConvOffsets::v1b, 512, net->v1);
-    dense(net->v1, 512, P + ConvOffsets::v2w, P + ConvOffsets::v2b, 256, net->v2);
+    dense(net->a3, 3136, PT + ConvOffsets::d1w, P + ConvOffsets::d1b, 512, net->d1);
+    dense(net->d1, 512, PT + ConvOffsets::d2w, P + ConvOffsets::d2b, 256, net->d2);
+    dense(net->d2, 256, PT + ConvOffsets::p1w, P + ConvOffsets::p1b, 512, net->p1);
+    dense(net->d2, 256, PT + ConvOffsets::v1w, P + ConvOffsets::v1b, 512, net->v1);
+    dense(net->v1, 512, PT + ConvOffsets::v2w, P + ConvOffsets::v2b, 256, net->v2);
     hipLaunchKernelGGL(heads_forward_kernel, dim3((n + 3) / 4), dim3(256), 0, st, net->p1, net->v2, P, n, net->cfg.scale, mu, sigma, vs);
     NET_HIP(net, hipGetLastError());
     return GRL_OK;
@@ -331,7 +353,7 @@ int grl_net_create(grl_handle *h, const grl_net_config *cfg, grl_net **out) {
     size_t c = n->chunk;
     int rc = GRL_OK;
     auto A = [&](float **p, size_t cnt) { if (rc == GRL_OK) rc = nalloc(n, p, cnt); };
-    A(&n->params, ConvOffsets::total); A(&n->grads, ConvOffsets::total); A(&n->adam_m, ConvOffsets::total); A(&n->adam_v, ConvOffsets::total);
+    A(&n->params, ConvOffsets::total); A(&n->paramsT, ConvOffsets::total); A(&n->grads, ConvOffsets::total); A(&n->adam_m, ConvOffsets::total); A(&n->adam_v, ConvOffsets::total);
     A(&n->a1, c * 12800); A(&n->a2, c * 5184); A(&n->a3, c * 3136); A(&n->d1, c * 512); A(&n->d2, c * 256);
     A(&n->p1, c * 512); A(&n->v1, c * 512); A(&n->v2, c * 256); A(&n->stats, 16);
     if (rc == GRL_OK) rc = ensure_tmp_obs(n, h->E);
@@ -365,6 +387,8 @@ int grl_net_set_params(grl_net *n, const float *host, int64_t cnt) {
     hipSetDevice(n->h->cfg.device_id);
     NET_HIP(n, hipStreamSynchronize(n->h->stream));
     NET_HIP(n, hipMemcpy(n->params, host, cnt * 4, hipMemcpyHostToDevice));
+    refresh_transposes(n);
+    NET_HIP(n, hipStreamSynchronize(n->h->stream));
     return GRL_OK;
 }
 

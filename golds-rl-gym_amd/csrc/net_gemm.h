@@ -4,16 +4,21 @@
 // fed_gym/agents/paac/policy_v_network.py:14-59) -- conv2, conv3 as implicit GEMMs over NHWC
 // activations, the dense stack, and their data/weight gradients -- go through two kernels:
 //
-//   gemm_rowk<BM,BN,WGM,WGN,B_ROWK>   C[M,N] = A[M,K] * B      (A rows gathered, K contiguous in runs)
-//        B_ROWK=false: B = W[K,N]  (forward)          B_ROWK=true: B = W[N,K]^T  (data gradient)
-//   gemm_tn<BM,BN,WGM,WGN>            C[I,J] = sum_m A[m,I] * B[m,J]   (weight gradient, split over m)
+//   gemm_rowk<BM,BN,WGM,WGN>   C[M,N] = A[M,K] * Bt[N,K]^T   (A rows gathered; both operands K-contiguous)
+//        forward: Bt = W^T (a transposed copy of the layer's kernel kept beside the parameters)
+//        data gradient: Bt = W itself (dX = dY * W^T), or a rearranged kernel for the transposed convs
+//   gemm_tn<BM,BN,WGM,WGN>     C[I,J] = sum_m A[m,I] * B[m,J]   (weight gradient, split over m into slabs)
 //
 // built on v_mfma_f32_32x32x2_f32 (exact f32, 64 FLOP/clk/SIMD = the fp32 peak of 157 TF; the
 // reference computes in float32, so no reduced-precision MFMA is used).  256 threads = 4 waves,
 // BK = 32, operands staged through LDS with register prefetch of the next K-tile so the global
-// loads fly under the 64-cycle MFMAs.  LDS layouts are chosen so the one-float-per-lane fragment
-// reads (lane l: row l&31, k = l>>5) are bank-conflict free: "RowK" tiles are [rows][33], "KRow"
-// tiles are [32][rows].
+// loads fly under the 64-cycle MFMAs.
+//
+// gemm_rowk LDS layout: both tiles are [rows][36] floats.  The MFMA's k index is a free
+// permutation as long as A and B agree, so lane half lk = lane>>5 owns k in [16*lk, 16*lk+16) and
+// fetches four consecutive k per ds_read_b128 (row stride 36 floats = 144 B puts the 16 lanes of
+// every b128 service group on 16 distinct 4-bank slots: conflict free).  4x fewer LDS instructions
+// than one ds_read_b32 per k.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -111,74 +116,71 @@ struct EpiGradStride2 {
     }
 };
 
-// ---------------------------------------------------------------------------- C = A(rowk) * B
-template <int BM, int BN, int WGM, int WGN, bool B_ROWK, class AG, class Epi>
-__global__ __launch_bounds__(256, 2) void gemm_rowk(AG ag, const float *__restrict__ Bw, int ldb, int N, Epi epi) {
-    constexpr int BK = 32, LDA = 33;
+// ---------------------------------------------------------------------------- C = A(rowk) * Bt^T
+template <int BM, int BN, int WGM, int WGN, class AG, class Epi>
+__global__ __launch_bounds__(256, 2) void gemm_rowk(AG ag, const float *__restrict__ Bt, int ldb, int N, Epi epi) {
+    constexpr int BK = 32, LD = 36;
     constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
     constexpr int NA = BM / 32;                       // float4 per thread for the A tile
     constexpr int NB = BN / 32;                       // float4 per thread for the B tile
     static_assert(WGM * WGN == 4 && TM >= 1 && TN >= 1, "4 waves");
-    __shared__ float As[BM * LDA];
-    __shared__ float Bs[B_ROWK ? BN * LDA : BK * BN];
+    __shared__ __attribute__((aligned(16))) float As[BM * LD];
+    __shared__ __attribute__((aligned(16))) float Bs[BN * LD];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave - wm * WGN;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int M = ag.rows, K = ag.K();
+    const int trow = tid >> 3, tk4 = (tid & 7) * 4;
 
-    // A rows owned by this thread: r = (tid>>3) + 32*i, k4 = tid&7
+    // A rows owned by this thread: r = trow + 32*i
     long aoff[NA];
     int ayx[NA];
     bool arow_ok[NA];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-        int r = m0 + (tid >> 3) + 32 * i;
+        int r = m0 + trow + 32 * i;
         arow_ok[i] = r < M;
         int iy0, ix0;
         ag.row(arow_ok[i] ? r : 0, aoff[i], iy0, ix0);
         ayx[i] = (iy0 << 16) | (ix0 & 0xFFFF);
     }
-    float4 ra[NA], rb[NB];
-#define GRL_LOAD_TILE(kt_)                                                                                         \
-    {                                                                                                              \
-        int toff, ty, tx;                                                                                          \
-        ag.tap((kt_) * BK, toff, ty, tx);                                                                          \
-        _Pragma("clang loop unroll(full)") for (int i = 0; i < NA; ++i) {                                                           \
-            int iy0 = ayx[i] >> 16, ix0 = (int)(int16_t)(ayx[i] & 0xFFFF);                                         \
-            bool v = arow_ok[i] && ag.ok(iy0, ix0, ty, tx);                                                        \
-            float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);                                                           \
-            if (v) t4 = *reinterpret_cast<const float4 *>(ag.base + aoff[i] + toff + (tid & 7) * 4);               \
-            ra[i].x = t4.x; ra[i].y = t4.y; ra[i].z = t4.z; ra[i].w = t4.w;                                        \
-        }                                                                                                          \
-        if (B_ROWK) { /* W[j][k], k contiguous: rows j = n0 + (tid>>3) + 32*i */                                   \
-            _Pragma("clang loop unroll(full)") for (int i = 0; i < NB; ++i) {                                                       \
-                int j = n0 + (tid >> 3) + 32 * i;                                                                  \
-                rb[i] = *reinterpret_cast<const float4 *>(Bw + (long)j * ldb + (kt_) * BK + (tid & 7) * 4);        \
-            }                                                                                                      \
-        } else { /* W[k][n], n contiguous: BN/4 float4 per k row */                                                \
-            _Pragma("clang loop unroll(full)") for (int i = 0; i < NB; ++i) {                                                       \
-                int idx = tid + 256 * i;                                                                           \
-                int kk = idx / (BN / 4), j4 = idx - kk * (BN / 4);                                                 \
-                rb[i] = *reinterpret_cast<const float4 *>(Bw + (long)((kt_) * BK + kk) * ldb + n0 + j4 * 4);       \
-            }                                                                                                      \
-        }                                                                                                          \
+    static_assert(NB == 1 || NB == 2 || NB == 4, "B tile of 32, 64 or 128 rows");
+    const float *brow0 = Bt + (long)(n0 + trow) * ldb + tk4;
+
+    float4 ra[NA];
+    float4 rb0 = make_float4(0.f, 0.f, 0.f, 0.f), rb1 = rb0, rb2 = rb0, rb3 = rb0;
+    unsigned vmask = 0;
+#define GRL_LOAD_TILE(kt_)                                                                                 \
+    {                                                                                                      \
+        int toff, ty, tx;                                                                                  \
+        ag.tap((kt_) * BK, toff, ty, tx);                                                                  \
+        _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                   \
+            int iy0 = ayx[i] >> 16, ix0 = (int)(int16_t)(ayx[i] & 0xFFFF);                                 \
+            bool v = arow_ok[i] && ag.ok(iy0, ix0, ty, tx);                                                \
+            /* unconditional load from a clamped address + select: no branch, so the compiler keeps all */ \
+            /* loads of the tile together at the top of the compute phase (prefetch distance = 1 tile) */  \
+            ra[i] = *reinterpret_cast<const float4 *>(ag.base + (v ? aoff[i] + toff : 0L) + tk4);          \
+            vmask = v ? (vmask | (1u << i)) : (vmask & ~(1u << i));   /* the zero-fill select happens at store time */ \
+        }                                                                                                  \
+        /* named scalars, not an array: an array here is "promoted" to LDS by the compiler */             \
+        rb0 = *reinterpret_cast<const float4 *>(brow0 + (kt_) * BK);                                       \
+        if (NB > 1) rb1 = *reinterpret_cast<const float4 *>(brow0 + (long)32 * ldb + (kt_) * BK);          \
+        if (NB > 2) rb2 = *reinterpret_cast<const float4 *>(brow0 + (long)64 * ldb + (kt_) * BK);          \
+        if (NB > 2) rb3 = *reinterpret_cast<const float4 *>(brow0 + (long)96 * ldb + (kt_) * BK);          \
     }
-#define GRL_STORE_TILE()                                                                                           \
-    {                                                                                                              \
-        _Pragma("clang loop unroll(full)") for (int i = 0; i < NA; ++i) {                                                           \
-            float *d = As + ((tid >> 3) + 32 * i) * LDA + (tid & 7) * 4;                                           \
-            d[0] = ra[i].x; d[1] = ra[i].y; d[2] = ra[i].z; d[3] = ra[i].w;                                        \
-        }                                                                                                          \
-        if (B_ROWK) {                                                                                              \
-            _Pragma("clang loop unroll(full)") for (int i = 0; i < NB; ++i) {                                                       \
-                float *d = Bs + ((tid >> 3) + 32 * i) * LDA + (tid & 7) * 4;                                       \
-                d[0] = rb[i].x; d[1] = rb[i].y; d[2] = rb[i].z; d[3] = rb[i].w;                                    \
-            }                                                                                                      \
-        } else {                                                                                                   \
-            _Pragma("clang loop unroll(full)") for (int i = 0; i < NB; ++i)                                                         \
-                *reinterpret_cast<float4 *>(Bs + (tid + 256 * i) * 4) = rb[i];                                     \
-        }                                                                                                          \
+#define GRL_STORE_TILE()                                                                                   \
+    {                                                                                                      \
+        _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                   \
+            const bool v = (vmask >> i) & 1u;                                                              \
+            float4 t4 = ra[i];                                                                             \
+            t4.x = v ? t4.x : 0.f; t4.y = v ? t4.y : 0.f; t4.z = v ? t4.z : 0.f; t4.w = v ? t4.w : 0.f;    \
+            *reinterpret_cast<float4 *>(As + (trow + 32 * i) * LD + tk4) = t4;                             \
+        }                                                                                                  \
+        *reinterpret_cast<float4 *>(Bs + trow * LD + tk4) = rb0;                                           \
+        if (NB > 1) *reinterpret_cast<float4 *>(Bs + (trow + 32) * LD + tk4) = rb1;                        \
+        if (NB > 2) *reinterpret_cast<float4 *>(Bs + (trow + 64) * LD + tk4) = rb2;                        \
+        if (NB > 2) *reinterpret_cast<float4 *>(Bs + (trow + 96) * LD + tk4) = rb3;                        \
     }
 
     f32x16 acc[TM][TN];
@@ -192,23 +194,34 @@ __global__ __launch_bounds__(256, 2) void gemm_rowk(AG ag, const float *__restri
     const int nk = K / BK;
     GRL_LOAD_TILE(0)
     const int lr = lane & 31, lk = lane >> 5;
+    const float *ap = As + (wm * WM + lr) * LD + lk * 16;
+    const float *bp = Bs + (wn * WN + lr) * LD + lk * 16;
     for (int kt = 0; kt < nk; ++kt) {
         GRL_STORE_TILE()
         __syncthreads();
-        if (kt + 1 < nk) GRL_LOAD_TILE(kt + 1)
+        {   // prefetch the next K-tile (the last iteration re-reads its own tile: branch-free)
+            const int ktn = kt + 1 < nk ? kt + 1 : kt;
+            GRL_LOAD_TILE(ktn)
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keep every global load above the MFMA phase
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            float af[TM], bf[TN];
+        for (int q = 0; q < 4; ++q) {
+            float4 af[TM], bf[TN];
 #pragma unroll
-            for (int a = 0; a < TM; ++a) af[a] = As[(wm * WM + a * 32 + lr) * LDA + kk + lk];
+            for (int a = 0; a < TM; ++a) af[a] = *reinterpret_cast<const float4 *>(ap + a * 32 * LD + q * 4);
 #pragma unroll
-            for (int b = 0; b < TN; ++b)
-                bf[b] = B_ROWK ? Bs[(wn * WN + b * 32 + lr) * LDA + kk + lk] : Bs[(kk + lk) * BN + wn * WN + b * 32 + lr];
+            for (int b = 0; b < TN; ++b) bf[b] = *reinterpret_cast<const float4 *>(bp + b * 32 * LD + q * 4);
 #pragma unroll
             for (int a = 0; a < TM; ++a)
 #pragma unroll
-                for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
+                for (int b = 0; b < TN; ++b) {
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].x, bf[b].x, acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].y, bf[b].y, acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].z, bf[b].z, acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].w, bf[b].w, acc[a][b], 0, 0, 0);
+                }
         }
+        __builtin_amdgcn_sched_barrier(0);   // ... and the LDS stores of the next tile below it
         __syncthreads();
     }
     // C/D map of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
@@ -230,7 +243,8 @@ __global__ __launch_bounds__(256, 2) void gemm_rowk(AG ag, const float *__restri
 // A element (m, i) = gathered patch element i of row m (same descriptors as above, i plays the role
 // of k); B = dY[m][J] dense.  Block (bi, bj, chunk) reduces rows [chunk*mc, (chunk+1)*mc) and writes
 // its partial tile to slab[chunk][I][J]; a follow-up kernel sums the slabs in a fixed order
-// (deterministic, unlike float atomics).
+// (deterministic, unlike float atomics).  Tiles are [32][rows] ("KRow"): fragment reads are
+// consecutive floats across lanes, conflict free.
 template <int BM, int BN, int WGM, int WGN, class AG>
 __global__ __launch_bounds__(256) void gemm_tn(AG ag, const float *__restrict__ dY, int J, int mc, float *__restrict__ slab) {
     constexpr int BK = 32;
@@ -238,8 +252,8 @@ __global__ __launch_bounds__(256) void gemm_tn(AG ag, const float *__restrict__ 
     constexpr int A4 = BM / 4, B4 = BN / 4;           // float4 per reduction row
     constexpr int NA = BK * A4 / 256, NB = BK * B4 / 256;
     static_assert(WGM * WGN == 4 && NA >= 1 && NB >= 1, "tile too small");
-    __shared__ float As[BK * BM];
-    __shared__ float Bs[BK * BN];
+    __shared__ __attribute__((aligned(16))) float As[BK * BM];
+    __shared__ __attribute__((aligned(16))) float Bs[BK * BN];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave - wm * WGN;
     const int i0 = blockIdx.x * BM, j0 = blockIdx.y * BN;
@@ -251,32 +265,43 @@ __global__ __launch_bounds__(256) void gemm_tn(AG ag, const float *__restrict__ 
     ag.tap(i0, toff, ty, tx);   // the BM-wide column run lies inside one tap row (checked on the host)
 
     float4 ra[NA], rb[NB];
+    unsigned vma = 0, vmb = 0;
 #define GRL_LOAD_TILE(mt_)                                                                                         \
     {                                                                                                              \
-        _Pragma("clang loop unroll(full)") for (int i = 0; i < NA; ++i) {                                                           \
+        _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                           \
             int idx = tid + 256 * i;                                                                               \
             int kk = idx / A4, c4 = idx - kk * A4;                                                                 \
             int m = (mt_) + kk;                                                                                    \
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                                                            \
-            if (m < mend) {                                                                                        \
-                long off; int iy0, ix0;                                                                            \
-                ag.row(m, off, iy0, ix0);                                                                          \
-                if (ag.ok(iy0, ix0, ty, tx)) v = *reinterpret_cast<const float4 *>(ag.base + off + toff + c4 * 4); \
-            }                                                                                                      \
-            ra[i] = v;                                                                                             \
+            const bool inr = m < mend;                                                                             \
+            long off; int iy0, ix0;                                                                                \
+            ag.row(inr ? m : mbeg, off, iy0, ix0);                                                                 \
+            const bool v = inr && ag.ok(iy0, ix0, ty, tx);                                                         \
+            ra[i] = *reinterpret_cast<const float4 *>(ag.base + (v ? off + toff : 0L) + c4 * 4);                   \
+            vma = v ? (vma | (1u << i)) : (vma & ~(1u << i));                                                      \
         }                                                                                                          \
-        _Pragma("clang loop unroll(full)") for (int i = 0; i < NB; ++i) {                                                           \
+        _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                           \
             int idx = tid + 256 * i;                                                                               \
             int kk = idx / B4, c4 = idx - kk * B4;                                                                 \
             int m = (mt_) + kk;                                                                                    \
-            rb[i] = m < mend ? *reinterpret_cast<const float4 *>(dY + (long)m * J + j0 + c4 * 4)                   \
-                             : make_float4(0.f, 0.f, 0.f, 0.f);                                                    \
+            const bool v = m < mend;                                                                               \
+            rb[i] = *reinterpret_cast<const float4 *>(dY + (long)(v ? m : mbeg) * J + j0 + c4 * 4);                \
+            vmb = v ? (vmb | (1u << i)) : (vmb & ~(1u << i));                                                      \
         }                                                                                                          \
     }
 #define GRL_STORE_TILE()                                                                                           \
     {                                                                                                              \
-        _Pragma("clang loop unroll(full)") for (int i = 0; i < NA; ++i) *reinterpret_cast<float4 *>(As + (tid + 256 * i) * 4) = ra[i]; \
-        _Pragma("clang loop unroll(full)") for (int i = 0; i < NB; ++i) *reinterpret_cast<float4 *>(Bs + (tid + 256 * i) * 4) = rb[i]; \
+        _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                           \
+            const bool v = (vma >> i) & 1u;                                                                        \
+            float4 t4 = ra[i];                                                                                     \
+            t4.x = v ? t4.x : 0.f; t4.y = v ? t4.y : 0.f; t4.z = v ? t4.z : 0.f; t4.w = v ? t4.w : 0.f;            \
+            *reinterpret_cast<float4 *>(As + (tid + 256 * i) * 4) = t4;                                            \
+        }                                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                           \
+            const bool v = (vmb >> i) & 1u;                                                                        \
+            float4 t4 = rb[i];                                                                                     \
+            t4.x = v ? t4.x : 0.f; t4.y = v ? t4.y : 0.f; t4.z = v ? t4.z : 0.f; t4.w = v ? t4.w : 0.f;            \
+            *reinterpret_cast<float4 *>(Bs + (tid + 256 * i) * 4) = t4;                                            \
+        }                                                                                                          \
     }
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -291,7 +316,11 @@ __global__ __launch_bounds__(256) void gemm_tn(AG ag, const float *__restrict__ 
         for (int mt = mbeg; mt < mend; mt += BK) {
             GRL_STORE_TILE()
             __syncthreads();
-            if (mt + BK < mend) GRL_LOAD_TILE(mt + BK)
+            {
+                const int mtn = mt + BK < mend ? mt + BK : mt;
+                GRL_LOAD_TILE(mtn)
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int kk = 0; kk < BK; kk += 2) {
                 float af[TM], bf[TN];
@@ -304,6 +333,7 @@ __global__ __launch_bounds__(256) void gemm_tn(AG ag, const float *__restrict__ 
 #pragma unroll
                     for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
         }
     }
@@ -322,13 +352,22 @@ __global__ __launch_bounds__(256) void gemm_tn(AG ag, const float *__restrict__ 
 #undef GRL_STORE_TILE
 }
 
-// dst[i] (+)= sum_c slab[c][i]   (fixed order -> bitwise reproducible)
+// dst[i] (+)= sum_c slab[c][i]   (fixed association: 4 strided partial sums, then a fixed tree -> bitwise
+// reproducible, and four independent load streams per lane)
 __global__ void slab_reduce_kernel(const float *__restrict__ slab, int chunks, long n, float *__restrict__ dst, int accumulate) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    float s = accumulate ? dst[i] : 0.f;
-    for (int c = 0; c < chunks; ++c) s += slab[(long)c * n + i];
-    dst[i] = s;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int c = 0;
+    for (; c + 3 < chunks; c += 4) {
+        s0 += slab[(long)c * n + i];
+        s1 += slab[(long)(c + 1) * n + i];
+        s2 += slab[(long)(c + 2) * n + i];
+        s3 += slab[(long)(c + 3) * n + i];
+    }
+    for (; c < chunks; ++c) s0 += slab[(long)c * n + i];
+    float s = (s0 + s1) + (s2 + s3);
+    dst[i] = accumulate ? dst[i] + s : s;
 }
 
 // column sums of dY[M][J] over row chunks -> slab[chunk][J]   (bias gradients)
