@@ -102,16 +102,17 @@ struct EpiGrad {   // dX[r][c] = (v [+ dX[r][c]]) * (fwd[r][c] > 0 if mask)
     }
 };
 
-// data gradient of conv2 for one parity class (py,px): row (n, yh, xh) -> pixel (2yh+py, 2xh+px) of
-// the [n][20][20][32] tensor
+// data gradient of conv2: the four pixel-parity classes (py,px) read the SAME 2x2 source taps and differ
+// only in their kernel, so they are the N = 4*32 columns of one GEMM: row (n, yh, xh), column cls*32 + c
+// -> pixel (2yh+py, 2xh+px), channel c of the [n][20][20][32] tensor
 struct EpiGradStride2 {
     float *dX;
     const float *fwd;
-    int py, px;
-    __device__ __forceinline__ void operator()(int r, int c, float v) const {
+    __device__ __forceinline__ void operator()(int r, int col, float v) const {
         int n = r / 100, q = r - n * 100;
         int yh = q / 10, xh = q - yh * 10;
-        long i = (((long)n * 20 + 2 * yh + py) * 20 + 2 * xh + px) * 32 + c;
+        int cls = col >> 5, c = col & 31;
+        long i = (((long)n * 20 + 2 * yh + (cls >> 1)) * 20 + 2 * xh + (cls & 1)) * 32 + c;
         dX[i] = fwd[i] > 0.f ? v : 0.f;
     }
 };
