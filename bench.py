@@ -84,16 +84,7 @@ class RandomPolicyRollout(object):
         eng.returns_device(self.rew, self.val, None, self.boot, T, E, self.gamma, 1.0, self.scale, 0.0, 0.0, self.y, self.adv)
 
 
-def cpu_baseline(sample_envs, T):
-    """The oracle's C restatement (oracle/oracle_c.c, kind 'port') on the host cores, bounded sample."""
-    from oracle import oracle_c as OC
-    rng = np.random.RandomState(0)
-    E = sample_envs
-    x, xa = rng.rand(E, 80, 2), rng.rand(E, 10, 2)
-    an, pn = rng.normal(size=(E, 10, 2)), rng.normal(size=(E, 80, 2))
-    act = rng.normal(size=(E, 10, 2)).astype(np.float32)
-    OC.swarm_step(x[:64], xa[:64], act[:64], an[:64], pn[:64], threads=1)
-    out = {}
+def _cpu_cores():
     ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:   # the GPU box grants a CPU share through the cgroup, not through affinity
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
@@ -101,20 +92,72 @@ def cpu_baseline(sample_envs, T):
             ncores = max(1, min(ncores, int(float(quota) / float(period) + 0.5)))
     except (OSError, ValueError):
         pass
-    ncores = min(ncores, 32)
+    return min(ncores, 32)
+
+
+def cpu_baseline(sample_envs, T, full_update_envs=4):
+    """CPU baseline from the oracle ("port"), bounded sample of the SAME workload: a full PAAC update
+    (dense 84x84x3 images as the reference builds them, conv policy forward per step, C env step + observation,
+    n-step returns, loss + backward over the T*E*10 samples) on `full_update_envs` envs; numpy/BLAS threads +
+    OpenMP on the granted cores.  The env-only rate of the C port on more envs is reported beside it."""
+    from oracle import nets as NN
+    from oracle import oracle as O
+    from oracle import oracle_c as OC
+    ncores = _cpu_cores()
+    try:
+        from threadpoolctl import threadpool_limits
+        limiter = threadpool_limits(limits=ncores)
+    except Exception:   # noqa: BLE001
+        limiter = None
+    rng = np.random.RandomState(0)
+    # ---- env-only (C port, OpenMP)
+    E = sample_envs
+    x, xa = rng.rand(E, 80, 2), rng.rand(E, 10, 2)
+    an, pn = rng.normal(size=(E, 10, 2)), rng.normal(size=(E, 80, 2))
+    act = rng.normal(size=(E, 10, 2)).astype(np.float32)
+    OC.swarm_step(x[:64], xa[:64], act[:64], an[:64], pn[:64], threads=1)
+    env_only = {}
     for label, threads in (("1core", 1), ("allcores", ncores)):
         xx, xxa = x.copy(), xa.copy()
         t0 = time.perf_counter()
-        used = 1
         for t in range(T):
             xx, xxa, _, _, _, _, used = OC.swarm_step(xx, xxa, act, an, pn, threads=threads)
-        dt = time.perf_counter() - t0
-        out[label] = (E * T / dt, used, dt)
-    v, used, dt = out["allcores"]
-    return {"value": v, "unit": "env-steps/s", "cores": used, "kind": "port",
-            "sample": "oracle/oracle_c.c (SwarmEnv.step + process_state only -- no policy network --, float64, OpenMP) on "
-                      "%d envs x %d steps, %.1f s total; 1 core: %.0f env-steps/s" % (E, T, dt + out["1core"][2], out["1core"][0]),
-            "value_1core": out["1core"][0]}
+        env_only[label] = E * T / (time.perf_counter() - t0)
+    # ---- full PAAC update on a few envs
+    Ef = full_update_envs
+    p = NN.conv_init(3)
+    x, xa = rng.rand(Ef, 80, 2), rng.rand(Ef, 10, 2)
+    an, pn = rng.normal(size=(Ef, 10, 2)), rng.normal(size=(Ef, 80, 2))
+
+    def images(x, xa):
+        out = []
+        for e in range(Ef):
+            lb, ab, pos = O.swarm_observe_compact(x[e], xa[e], 84)
+            out.append(O.swarm_local_states(O.swarm_grid_from_compact(lb, ab, 84), pos))
+        return np.concatenate(out).astype(np.float32).astype(np.float64)
+    t0 = time.perf_counter()
+    states, actions, values, rewards = [], [], [], []
+    for t in range(T):
+        s = images(x, xa)
+        mu, sigma, vs = NN.conv_forward(p, s, 1000.0)
+        a = mu + sigma * rng.normal(size=mu.shape)
+        env_a = O.swarm_transform_actions(a).reshape(Ef, 10, 2).astype(np.float32)
+        x, xa, r, _, _, _, _ = OC.swarm_step(x, xa, env_a, an, pn, threads=ncores)
+        states.append(s); actions.append(a); values.append(vs); rewards.append(np.repeat(r, 10))
+    _, _, boot = NN.conv_forward(p, images(x, xa), 1000.0)
+    y, adv = O.nstep_returns(np.array(rewards), np.array(values), boot, 0.99)
+    loss, _, _, g, _ = NN.conv_loss_and_grads(p, np.concatenate(states), np.concatenate(actions), (adv / 1000.0).reshape(-1),
+                                              y.reshape(-1), 0.02, 1000.0)
+    gf, _ = NN.clip_by_global_norm(NN.flatten_params(g), 40.0)
+    NN.adam_step(NN.flatten_params(p), gf, np.zeros_like(gf), np.zeros_like(gf), 1, 1e-4)
+    dt = time.perf_counter() - t0
+    if limiter is not None:
+        limiter.restore_original_limits() if hasattr(limiter, "restore_original_limits") else None
+    return {"value": Ef * T / dt, "unit": "env-steps/s", "cores": ncores, "kind": "port",
+            "sample": "oracle full PAAC update (oracle/nets.py float64 numpy conv policy fwd+bwd+clip+Adam, oracle/oracle_c.c env "
+                      "step+observation, dense 84x84x3 images as the reference feeds them) on %d envs x %d steps: %.1f s" % (Ef, T, dt),
+            "env_only_value": env_only["allcores"], "env_only_value_1core": env_only["1core"],
+            "env_only_sample": "oracle/oracle_c.c SwarmEnv.step + process_state on %d envs x %d steps, OpenMP" % (E, T)}
 
 
 def timed(run, wait, steps):
