@@ -79,6 +79,7 @@ static bool field_info(grl_handle *h, int32_t f, FieldInfo &fi) {
             case GRL_FLD_TRADE_QUANTITY: fi = {h->tr.q, 4, n, true}; return true;
             case GRL_FLD_TRADE_PRICES: fi = {h->tr.p, 4, n, true}; return true;
             case GRL_FLD_TRADE_NORMALS: fi = {h->tr.normals, 4, n, true}; return true;
+            case GRL_FLD_NHIST: fi = {h->tr.nhist, 4, 1, false}; return true;
             default: return false;
         }
     }
@@ -141,6 +142,8 @@ int grl_create(const grl_config *cfg, grl_handle **out) {
         if (cfg->solow_tape_len < 2 || (cfg->solow_tape_len & 1)) return fail(nullptr, GRL_E_INVALID, "grl_create: solow_tape_len must be even and >= 2");
         if (cfg->rnn_length < 1 || cfg->rnn_length > 16) return fail(nullptr, GRL_E_INVALID, "grl_create: rnn_length must be in 1..16");
     }
+    if (cfg->env_kind == GRL_ENV_TRADE && (cfg->rnn_length < 1 || cfg->rnn_length > 32))
+        return fail(nullptr, GRL_E_INVALID, "grl_create: rnn_length must be in 1..32");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0)

@@ -42,6 +42,7 @@ struct TradeState {
     float *cash, *assets, *q, *p;     // q,p (n,E) asset-major
     float *normals;                   // (n,E) injected
     uint32_t *nstep;                  // generator counter per env
+    int32_t *nhist;                   // states in the (PAAC-style) worker history list, as SolowState::nhist
     float *obs_raw, *obs;             // (E,1+2n)
     float std_e;
 };

@@ -245,7 +245,8 @@ struct TradeParams {
     float *cash, *assets, *q, *p;
     const float *normals;
     uint32_t *nstep;
-    int32_t *elapsed, *episode;
+    int32_t *elapsed, *episode, *nhist;
+    int rnn;
     const float *actions;
     float *reward;
     uint8_t *done;
@@ -297,6 +298,7 @@ __global__ __launch_bounds__(256) void trade_step_kernel(TradeParams R) {
             cash = 10.f;
             R.assets[env] = 10.f;
             R.elapsed[env] = 0;
+            R.nhist[env] = 1;            // histories[i] = [reset state]  (emulator_runner.py:52)
             R.episode[env] = R.episode[env] + 1;
             for (int a = 0; a < n; ++a) {
                 R.q[a * E + env] = 0.f; R.p[a * E + env] = 1.f;
@@ -306,6 +308,10 @@ __global__ __launch_bounds__(256) void trade_step_kernel(TradeParams R) {
         } else {
             R.assets[env] = assets;
             R.elapsed[env] = el;
+            {
+                int nh = R.nhist[env] + 1;
+                R.nhist[env] = nh > R.rnn + 1 ? R.rnn + 1 : nh;     // list trimmed to rnn+1 (emulator_runner.py:61)
+            }
             const int pairs = (n + 1) / 2;
             for (int a = 0; a < n; a += 2) {
                 double z0, z1;
@@ -346,6 +352,7 @@ __global__ void trade_reset_kernel(TradeParams R) {
     const int n = R.n, S = 1 + 2 * n;
     const size_t E = R.E;
     R.cash[env] = 10.f; R.assets[env] = 10.f; R.elapsed[env] = 0; R.episode[env] = R.episode[env] + 1;
+    R.nhist[env] = 0;     // explicit reset: the worker's list starts empty (emulator_runner.py:23)
     float *oraw = R.obs_raw + (size_t)env * S, *o = R.obs + (size_t)env * S;
     oraw[0] = 10.f; o[0] = trade_proc(0, 10.f);
     for (int a = 0; a < n; ++a) {
@@ -373,7 +380,7 @@ __global__ void trade_observe_kernel(TradeParams R) {
 static TradeParams trade_params(grl_handle *h) {
     TradeParams R{};
     R.cash = h->tr.cash; R.assets = h->tr.assets; R.q = h->tr.q; R.p = h->tr.p; R.normals = h->tr.normals;
-    R.nstep = h->tr.nstep; R.elapsed = h->elapsed; R.episode = h->episode; R.reward = h->reward; R.done = h->done;
+    R.nstep = h->tr.nstep; R.nhist = h->tr.nhist; R.rnn = h->cfg.rnn_length; R.elapsed = h->elapsed; R.episode = h->episode; R.reward = h->reward; R.done = h->done;
     R.obs_raw = h->tr.obs_raw; R.obs = h->tr.obs; R.done_list = h->done_list; R.done_count = h->done_count;
     R.err_flag = h->err_flag; R.E = h->E; R.n = h->cfg.n_assets; R.max_steps = h->cfg.max_episode_steps;
     R.std_e = h->tr.std_e; R.flags = h->cfg.flags; R.env_off = (uint32_t)h->cfg.env_id_offset; R.seed = h->cfg.seed;
@@ -391,6 +398,7 @@ int trade_alloc(grl_handle *h) {
     if ((rc = dmalloc(h, &h->tr.p, E * n))) return rc;
     if ((rc = dmalloc(h, &h->tr.normals, E * n))) return rc;
     if ((rc = dmalloc(h, &h->tr.nstep, E))) return rc;
+    if ((rc = dmalloc(h, &h->tr.nhist, E))) return rc;
     if ((rc = dmalloc(h, &h->tr.obs_raw, E * (1 + 2 * n)))) return rc;
     if ((rc = dmalloc(h, &h->tr.obs, E * (1 + 2 * n)))) return rc;
     return GRL_OK;

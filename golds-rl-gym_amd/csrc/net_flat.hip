@@ -1,6 +1,7 @@
 // FlatPolicyVNetwork on gfx950 (reference fed_gym/agents/paac/policy_v_network.py:194-264 with the GRU
 // trunk of fed_gym/agents/a3c/estimators.py:5-28), its loss/backward/optimiser and the flat PAAC rollout
-// (fed_gym/agents/paac/paac.py:119-187) for the Solow handle.
+// (fed_gym/agents/paac/paac.py:119-187) for Solow handles and, PAAC-style, TradeAR1 handles (BASELINE config 5:
+// obs transform of a3c/worker.py:420-431, tanh actions :440-442, hyper-parameters of scripts/train_trade.py:38-40,119).
 //
 // The net has ~31k parameters and a few tens of kMAC per sample; BASELINE config 2 (4 096 envs) is
 // launch/latency bound, so the design goal is FEW LAUNCHES, not MFMA: one lane per sample,
@@ -66,6 +67,8 @@ struct FlatArgs {
     int n, S0, D, T, A;
     float scale, bound;
     const float *states, *hist;     // (n,S0) (n,T,D) row-major
+    const int32_t *nhist;           // if set: hist is NOT read; row t of sample s is states[s] for t < min(nhist[s],T), else 0
+                                    // (the PAAC worker's window, quirk Q11; needs D == S0)
     float *mu, *sigma, *vs;         // (n,A) (n,A) (n)
     float *ws;                      // [feature][n] or nullptr (inference)
     // backward only
@@ -111,12 +114,16 @@ __global__ __launch_bounds__(64) void flat_forward_kernel(FlatArgs a) {
     const int D = a.D, T = a.T, A = a.A, n = a.n;
     const WsOff wo = ws_offsets(T, A);
     float *ws = a.ws;
-    const float *hrow = a.hist + (long)ss * T * D;
+    const bool synth = a.nhist != nullptr;
+    const float *hrow = synth ? a.states + (long)ss * a.S0 : a.hist + (long)ss * T * D;
+    const int hstep = synth ? 0 : D;      // synthesized window: every valid row is the current state
+    int nrows = T;
+    if (synth) { int nh = a.nhist[ss]; nh = nh < 1 ? 1 : nh; nrows = nh < T ? nh : T; }
     // true_length (a3c/estimators.py:11-15): number of rows with a non-zero entry
     int len = 0;
     for (int t = 0; t < T; ++t) {
         float m = 0.f;
-        for (int i = 0; i < D; ++i) m = fmaxf(m, fabsf(hrow[t * D + i]));
+        for (int i = 0; i < D; ++i) m = fmaxf(m, fabsf(t < nrows ? hrow[t * hstep + i] : 0.f));
         len += m > 0.f ? 1 : 0;
     }
     float h[FH];
@@ -124,7 +131,7 @@ __global__ __launch_bounds__(64) void flat_forward_kernel(FlatArgs a) {
     for (int i = 0; i < FH; ++i) h[i] = 0.f;
     for (int t = 0; t < T; ++t) {
         // GRUCell (TF 1.4): r,u = sigmoid([x,h] Wg + bg); c = tanh([x, r*h] Wc + bc); h' = u*h + (1-u)*c
-        for (int i = 0; i < D; ++i) bufA[i * LS + lane] = hrow[t * D + i];
+        for (int i = 0; i < D; ++i) bufA[i * LS + lane] = t < nrows ? hrow[t * hstep + i] : 0.f;
 #pragma unroll
         for (int i = 0; i < FH; ++i) bufA[(D + i) * LS + lane] = h[i];
         float g[2 * FH];
@@ -342,17 +349,21 @@ __global__ __launch_bounds__(64) void flat_backward_kernel(FlatArgs a) {
 #pragma unroll
         for (int i = 0; i < FH; ++i) dh[i] = bufT[i * LS + lane];
         // ---- GRU, back through time with the sequence-length mask
-        const float *hrow = a.hist + (long)ss * T * D;
+        const bool synth = a.nhist != nullptr;
+        const float *hrow = synth ? a.states + (long)ss * a.S0 : a.hist + (long)ss * T * D;
+        const int hstep = synth ? 0 : D;
+        int nrows = T;
+        if (synth) { int nh = a.nhist[ss]; nh = nh < 1 ? 1 : nh; nrows = nh < T ? nh : T; }
         int len = 0;
         for (int t = 0; t < T; ++t) {
             float m = 0.f;
-            for (int i = 0; i < D; ++i) m = fmaxf(m, fabsf(hrow[t * D + i]));
+            for (int i = 0; i < D; ++i) m = fmaxf(m, fabsf(t < nrows ? hrow[t * hstep + i] : 0.f));
             len += (valid && m > 0.f) ? 1 : 0;
         }
         for (int t = T - 1; t >= 0; --t) {
             const bool act = t < len;
             __syncthreads();
-            for (int i = 0; i < D; ++i) bufA[i * LS + lane] = valid ? hrow[t * D + i] : 0.f;
+            for (int i = 0; i < D; ++i) bufA[i * LS + lane] = (valid && t < nrows) ? hrow[t * hstep + i] : 0.f;
 #pragma unroll
             for (int i = 0; i < FH; ++i) {
                 const float hp = W(ws_step(t) + i), r = W(ws_step(t) + FH + i), u = W(ws_step(t) + 2 * FH + i), c = W(ws_step(t) + 3 * FH + i);
@@ -466,6 +477,7 @@ struct grl_fnet {
     // rollout
     int T;
     float *ro_states, *ro_hist, *ro_act, *ro_envact, *ro_val, *ro_rew, *ro_mask, *ro_y, *ro_adv, *ro_boot;
+    int32_t *ro_nhist;
     unsigned long act_counter;
     std::vector<void *> allocs;
 };
@@ -490,16 +502,18 @@ static int falloc(grl_fnet *n, T **p, size_t count) {
     return GRL_OK;
 }
 
-static FlatArgs base_args(grl_fnet *net, int n, const float *states, const float *hist, float *mu, float *sigma, float *vs, bool save) {
+static FlatArgs base_args(grl_fnet *net, int n, const float *states, const float *hist, float *mu, float *sigma, float *vs, bool save,
+                          const int32_t *nhist = nullptr) {
     FlatArgs a{};
     a.P = net->params; a.o = net->off; a.n = n; a.S0 = net->cfg.static_size; a.D = net->cfg.temporal_size; a.T = net->cfg.rnn_length;
     a.A = net->cfg.num_actions; a.scale = net->cfg.scale; a.bound = net->cfg.mu_bound; a.states = states; a.hist = hist;
-    a.mu = mu; a.sigma = sigma; a.vs = vs; a.ws = save ? net->ws : nullptr;
+    a.mu = mu; a.sigma = sigma; a.vs = vs; a.ws = save ? net->ws : nullptr; a.nhist = nhist;
     return a;
 }
 
-static int launch_forward(grl_fnet *net, int n, const float *states, const float *hist, float *mu, float *sigma, float *vs, bool save) {
-    FlatArgs a = base_args(net, n, states, hist, mu, sigma, vs, save);
+static int launch_forward(grl_fnet *net, int n, const float *states, const float *hist, float *mu, float *sigma, float *vs, bool save,
+                          const int32_t *nhist = nullptr) {
+    FlatArgs a = base_args(net, n, states, hist, mu, sigma, vs, save, nhist);
     hipLaunchKernelGGL(flat_forward_kernel, dim3((n + 63) / 64), dim3(64), FLAT_LDS_BYTES, net->h->stream, a);
     FNET_HIP(net, hipGetLastError());
     return GRL_OK;
@@ -507,16 +521,16 @@ static int launch_forward(grl_fnet *net, int n, const float *states, const float
 
 // forward(save) + backward over n device-resident samples; grads <- mean-loss gradient; optional Adam
 static int train_device(grl_fnet *net, int n, const float *states, const float *hist, const float *actions, const float *adv, const float *y,
-                        float lr, int apply_update, float *stats_host) {
+                        float lr, int apply_update, float *stats_host, const int32_t *nhist = nullptr) {
     hipStream_t st = net->h->stream;
     if (n > net->cfg.max_samples) return ffail(net, GRL_E_SIZE, "train: n exceeds max_samples of the net");
-    int rc = launch_forward(net, n, states, hist, net->mu, net->sigma, net->vs, true);
+    int rc = launch_forward(net, n, states, hist, net->mu, net->sigma, net->vs, true, nhist);
     if (rc) return rc;
     int groups = (n + 63) / 64;
     int blocks = groups < net->slab_blocks ? groups : net->slab_blocks;
     FNET_HIP(net, hipMemsetAsync(net->slab, 0, (size_t)blocks * net->off.total * 4, st));
     FNET_HIP(net, hipMemsetAsync(net->stats64, 0, 4 * sizeof(double), st));
-    FlatArgs a = base_args(net, n, states, hist, net->mu, net->sigma, net->vs, true);
+    FlatArgs a = base_args(net, n, states, hist, net->mu, net->sigma, net->vs, true, nhist);
     a.actions = actions; a.adv = adv; a.y = y; a.inv_n = 1.0f / (float)n; a.slab = net->slab; a.stats64 = net->stats64;
     hipLaunchKernelGGL(flat_backward_kernel, dim3(blocks), dim3(64), FLAT_LDS_BYTES, st, a);
     hipLaunchKernelGGL(flat_slab_reduce_kernel, dim3((unsigned)((net->off.total + 255) / 256)), dim3(256), 0, st, net->slab, blocks,
@@ -643,9 +657,17 @@ int grl_fnet_predict(grl_fnet *net, int32_t n, const float *states, const float 
 
 static int check_env(grl_fnet *net) {
     grl_handle *h = net->h;
-    if (h->cfg.env_kind != GRL_ENV_SOLOW || net->cfg.static_size != 2 || net->cfg.temporal_size != 2 ||
-        net->cfg.rnn_length != h->cfg.rnn_length || net->cfg.num_actions != 1)
-        return ffail(net, GRL_E_INVALID, "this call needs a Solow handle and a net with static=temporal=2, num_actions=1, the handle's rnn_length");
+    if (h->cfg.env_kind == GRL_ENV_SOLOW) {
+        if (net->cfg.static_size != 2 || net->cfg.temporal_size != 2 || net->cfg.rnn_length != h->cfg.rnn_length || net->cfg.num_actions != 1)
+            return ffail(net, GRL_E_INVALID, "a Solow handle needs a net with static=temporal=2, num_actions=1 and the handle's rnn_length");
+    } else if (h->cfg.env_kind == GRL_ENV_TRADE) {
+        const int S = 1 + 2 * h->cfg.n_assets;      // INPUT_SIZE = TEMPORAL_SIZE = 1+2n, NUM_ACTIONS = n (train_trade.py:38-40)
+        if (net->cfg.static_size != S || net->cfg.temporal_size != S || net->cfg.num_actions != h->cfg.n_assets ||
+            net->cfg.rnn_length != h->cfg.rnn_length)
+            return ffail(net, GRL_E_INVALID, "a TradeAR1 handle needs a net with static=temporal=1+2n, num_actions=n and the handle's rnn_length");
+    } else {
+        return ffail(net, GRL_E_INVALID, "this call needs a Solow or TradeAR1 handle");
+    }
     if (h->E > net->cfg.max_samples) return ffail(net, GRL_E_SIZE, "num_envs exceeds max_samples of the net");
     return GRL_OK;
 }
@@ -656,7 +678,9 @@ int grl_fnet_predict_env(grl_fnet *net, float *mu, float *sigma, float *vs) {
     int rc = check_env(net);
     if (rc) return rc;
     grl_handle *h = net->h;
-    if ((rc = launch_forward(net, h->E, h->so.obs, h->so.history, net->mu, net->sigma, net->vs, false))) return rc;
+    if (h->cfg.env_kind == GRL_ENV_SOLOW) rc = launch_forward(net, h->E, h->so.obs, h->so.history, net->mu, net->sigma, net->vs, false);
+    else rc = launch_forward(net, h->E, h->tr.obs, nullptr, net->mu, net->sigma, net->vs, false, h->tr.nhist);
+    if (rc) return rc;
     return fdownload(net, h->E, mu, sigma, vs);
 }
 
@@ -681,30 +705,45 @@ int grl_fnet_rollout(grl_fnet *net, int32_t T) {
     int rc = check_env(net);
     if (rc) return rc;
     grl_handle *h = net->h;
-    const int E = h->E, R = net->cfg.rnn_length;
+    const bool solow = h->cfg.env_kind == GRL_ENV_SOLOW;
+    const int E = h->E, R = net->cfg.rnn_length, S0 = net->cfg.static_size, A = net->cfg.num_actions;
     if ((long)T * E > net->cfg.max_samples) return ffail(net, GRL_E_SIZE, "grl_fnet_rollout: T*num_envs exceeds max_samples");
     if (!net->ro_states || net->T < T) {
         auto Al = [&](float **p, size_t cnt) { if (rc == GRL_OK) rc = falloc(net, p, cnt); };
-        Al(&net->ro_states, (size_t)T * E * 2); Al(&net->ro_hist, (size_t)T * E * R * 2); Al(&net->ro_act, (size_t)T * E);
-        Al(&net->ro_envact, E); Al(&net->ro_val, (size_t)T * E); Al(&net->ro_rew, (size_t)T * E); Al(&net->ro_mask, (size_t)T * E);
+        Al(&net->ro_states, (size_t)T * E * S0); Al(&net->ro_act, (size_t)T * E * A);
+        Al(&net->ro_envact, (size_t)E * A); Al(&net->ro_val, (size_t)T * E); Al(&net->ro_rew, (size_t)T * E); Al(&net->ro_mask, (size_t)T * E);
         Al(&net->ro_y, (size_t)T * E); Al(&net->ro_adv, (size_t)T * E); Al(&net->ro_boot, E);
+        if (solow) Al(&net->ro_hist, (size_t)T * E * R * 2);
+        else if (rc == GRL_OK) rc = falloc(net, &net->ro_nhist, (size_t)T * E);
         if (rc) return rc;
     }
     net->T = T;
     hipStream_t st = h->stream;
+    const float *obs = solow ? h->so.obs : h->tr.obs;
     for (int t = 0; t < T; ++t) {
-        // states[t] = shared_states, histories[t] = shared_histories (paac.py:132-133)
-        FNET_HIP(net, hipMemcpyAsync(net->ro_states + (size_t)t * E * 2, h->so.obs, (size_t)E * 8, hipMemcpyDeviceToDevice, st));
-        FNET_HIP(net, hipMemcpyAsync(net->ro_hist + (size_t)t * E * R * 2, h->so.history, (size_t)E * R * 8, hipMemcpyDeviceToDevice, st));
-        if ((rc = launch_forward(net, E, h->so.obs, h->so.history, net->mu, net->sigma, net->ro_val + (size_t)t * E, false))) return rc;
-        hipLaunchKernelGGL(flat_sample_kernel, dim3((E + 255) / 256), dim3(256), 0, st, net->mu, net->sigma, E, 1, h->cfg.seed,
-                           (uint32_t)h->cfg.env_id_offset, (uint32_t)net->act_counter, GRL_ENV_SOLOW, net->ro_act + (size_t)t * E, net->ro_envact);
+        // states[t] = shared_states, histories[t] = shared_histories (paac.py:132-133).  For TradeAR1 the window is
+        // kept as (state, #rows): the worker's history is min(n, rnn) copies of the current state (quirk Q11)
+        FNET_HIP(net, hipMemcpyAsync(net->ro_states + (size_t)t * E * S0, obs, (size_t)E * S0 * 4, hipMemcpyDeviceToDevice, st));
+        if (solow) {
+            FNET_HIP(net, hipMemcpyAsync(net->ro_hist + (size_t)t * E * R * 2, h->so.history, (size_t)E * R * 8, hipMemcpyDeviceToDevice, st));
+            rc = launch_forward(net, E, obs, h->so.history, net->mu, net->sigma, net->ro_val + (size_t)t * E, false);
+        } else {
+            FNET_HIP(net, hipMemcpyAsync(net->ro_nhist + (size_t)t * E, h->tr.nhist, (size_t)E * 4, hipMemcpyDeviceToDevice, st));
+            rc = launch_forward(net, E, obs, nullptr, net->mu, net->sigma, net->ro_val + (size_t)t * E, false, h->tr.nhist);
+        }
+        if (rc) return rc;
+        hipLaunchKernelGGL(flat_sample_kernel, dim3((E * A + 255) / 256), dim3(256), 0, st, net->mu, net->sigma, E, A, h->cfg.seed,
+                           (uint32_t)h->cfg.env_id_offset, (uint32_t)net->act_counter, h->cfg.env_kind, net->ro_act + (size_t)t * E * A,
+                           net->ro_envact);
         net->act_counter += 1;
-        if ((rc = solow_launch_step(h, net->ro_envact))) return ffail(net, rc, h->err);
+        rc = solow ? solow_launch_step(h, net->ro_envact) : trade_launch_step(h, net->ro_envact);
+        if (rc) return ffail(net, rc, h->err);
         FNET_HIP(net, hipMemcpyAsync(net->ro_rew + (size_t)t * E, h->reward, (size_t)E * 4, hipMemcpyDeviceToDevice, st));
         hipLaunchKernelGGL(flat_mask_kernel, dim3((E + 255) / 256), dim3(256), 0, st, h->done, E, net->ro_mask + (size_t)t * E);
     }
-    if ((rc = launch_forward(net, E, h->so.obs, h->so.history, net->mu, net->sigma, net->ro_boot, false))) return rc;
+    rc = solow ? launch_forward(net, E, obs, h->so.history, net->mu, net->sigma, net->ro_boot, false)
+               : launch_forward(net, E, obs, nullptr, net->mu, net->sigma, net->ro_boot, false, h->tr.nhist);
+    if (rc) return rc;
     // rewards clipped to [-2, 2] (paac.py:145), masked n-step return (paac.py:167-172), adv / scale (paac.py:177)
     if ((rc = launch_returns(h, net->ro_rew, net->ro_val, net->ro_mask, net->ro_boot, T, E, net->cfg.gamma, 1.0f, net->cfg.scale, -2.f, 2.f,
                              net->ro_y, net->ro_adv)))
@@ -718,7 +757,9 @@ int grl_fnet_train_rollout(grl_fnet *net, float lr, float *stats_host) {
     if (!net || !net->ro_states || net->T <= 0) return ffail(net, GRL_E_STATE, "grl_fnet_train_rollout: no rollout to train on");
     hipSetDevice(net->h->cfg.device_id);
     const int n = net->T * net->h->E;
-    return train_device(net, n, net->ro_states, net->ro_hist, net->ro_act, net->ro_adv, net->ro_y, lr, 1, stats_host);
+    if (net->h->cfg.env_kind == GRL_ENV_SOLOW)
+        return train_device(net, n, net->ro_states, net->ro_hist, net->ro_act, net->ro_adv, net->ro_y, lr, 1, stats_host);
+    return train_device(net, n, net->ro_states, nullptr, net->ro_act, net->ro_adv, net->ro_y, lr, 1, stats_host, net->ro_nhist);
 }
 
 int grl_fnet_read_rollout(grl_fnet *net, const char *which, void *host, size_t bytes) {
@@ -729,16 +770,18 @@ int grl_fnet_read_rollout(grl_fnet *net, const char *which, void *host, size_t b
     const size_t TE = (size_t)net->T * net->h->E;
     const void *src = nullptr;
     size_t need = TE * 4;
-    if (w == "actions") src = net->ro_act;
+    if (w == "actions") { src = net->ro_act; need = TE * net->cfg.num_actions * 4; }
     else if (w == "values") src = net->ro_val;
     else if (w == "rewards") src = net->ro_rew;
     else if (w == "masks") src = net->ro_mask;
     else if (w == "y") src = net->ro_y;
     else if (w == "adv") src = net->ro_adv;
     else if (w == "boot") { src = net->ro_boot; need = (size_t)net->h->E * 4; }
-    else if (w == "states") { src = net->ro_states; need = TE * 8; }
+    else if (w == "states") { src = net->ro_states; need = TE * net->cfg.static_size * 4; }
     else if (w == "histories") { src = net->ro_hist; need = TE * net->cfg.rnn_length * 8; }
+    else if (w == "nhist") { src = net->ro_nhist; need = TE * 4; }
     else return ffail(net, GRL_E_INVALID, "grl_fnet_read_rollout: unknown buffer '" + w + "'");
+    if (!src) return ffail(net, GRL_E_INVALID, "grl_fnet_read_rollout: '" + w + "' does not exist for this env kind");
     if (need != bytes) return ffail(net, GRL_E_SIZE, "grl_fnet_read_rollout: '" + w + "' needs " + std::to_string(need) + " bytes");
     FNET_HIP(net, hipStreamSynchronize(net->h->stream));
     FNET_HIP(net, hipMemcpy(host, src, bytes, hipMemcpyDeviceToHost));

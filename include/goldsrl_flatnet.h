@@ -57,11 +57,14 @@ int grl_fnet_predict_env(grl_fnet *net, float *mu, float *sigma, float *vs);
  * stats_host: {loss, policy_loss, critic_loss_mean, global_norm}.  apply_update=0: gradients only. */
 int grl_fnet_train(grl_fnet *net, int32_t n, const float *states, const float *history, const float *actions,
                    const float *advantages, const float *critic_target, float lr, int32_t apply_update, float *stats_host);
-/* Device-resident PAAC rollout on the Solow handle (paac.py:119-172): T x [forward, a = mu + sigma*N(0,1),
- * sigmoid, env step/auto-reset/observe/history], bootstrap, reward clip +-2, MASKED n-step returns. Async. */
+/* Device-resident PAAC rollout on a Solow or TradeAR1 handle (paac.py:119-172): T x [forward, a = mu + sigma*N(0,1),
+ * sigmoid (Solow) / tanh (TradeAR1), env step/auto-reset/observe/history], bootstrap, reward clip +-2, MASKED n-step
+ * returns.  TradeAR1 (BASELINE config 5; the reference has no PAAC runner for it) uses the net with
+ * static_size = temporal_size = 1+2n, num_actions = n and the worker-style history window (quirk Q11). Async. */
 int grl_fnet_rollout(grl_fnet *net, int32_t T);
 int grl_fnet_train_rollout(grl_fnet *net, float lr, float *stats_host);
-/* "actions" (T,E,A) "values" (T,E) "rewards" (T,E) raw "masks" (T,E) "y" (T,E) "adv" (T,E) "boot" (E,) */
+/* "actions" (T,E,A) "values" (T,E) "rewards" (T,E) raw "masks" (T,E) "y" (T,E) "adv" (T,E) "boot" (E,)
+ * "states" (T,E,S0); Solow: "histories" (T,E,rnn,2); TradeAR1: "nhist" (T,E) int32 rows of the window */
 int grl_fnet_read_rollout(grl_fnet *net, const char *which, void *host, size_t bytes);
 
 #ifdef __cplusplus

@@ -113,3 +113,53 @@ def test_flat_paac_rollout_on_solow_engine():
     # one more rollout with the updated weights still runs (values change)
     net.rollout(T); eng.wait()
     assert not np.array_equal(net.read_rollout("values", (T, E)), vals)
+
+
+def test_trade_paac_rollout_gru_policy():
+    """BASELINE config 5 shape: TradeAR1 n=16, GRU policy (static = temporal = 33, 16 actions, window 20)."""
+    from goldsrl import _ffi, _ffi_flat
+    E, T, n, R = 192, 6, 16, 20
+    S = 1 + 2 * n
+    eng = _ffi.Engine(_ffi.ENV_TRADE, E, seed=9, n_assets=n, rnn_length=R, max_episode_steps=4)
+    eng.reset()
+    net = _ffi_flat.FlatNet(eng, static_size=S, temporal_size=S, rnn_length=R, num_actions=n, max_samples=E * T, scale=100.0)
+    p = _params(net, S, S, n)
+    obs0 = eng.read("obs")
+    pred = net.predict_env()
+    hist0 = np.zeros((E, R, S)); hist0[:, 0] = obs0                 # one row after an explicit reset
+    mu, sigma, vs = NN.flat_forward(p, obs0.astype(np.float64), hist0, 100.0)
+    np.testing.assert_allclose(pred["mu"], mu, rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(pred["vs"], vs, rtol=2e-5, atol=2e-4)
+    net.rollout(T); eng.wait()
+    acts = net.read_rollout("actions", (T, E, n)); vals = net.read_rollout("values", (T, E)); rews = net.read_rollout("rewards", (T, E))
+    masks = net.read_rollout("masks", (T, E)); boot = net.read_rollout("boot", (E,))
+    nh = np.empty((T, E), np.int32); net._check(net.lib.grl_fnet_read_rollout(net.n, b"nhist", _ffi._ptr(nh), nh.nbytes))
+    st = net.read_rollout("states", (T, E, S))
+    assert np.array_equal(vals[0], pred["vs"])
+    # window rows: 0 (shown as 1) after the explicit reset, then 1,2,3, reset at the TimeLimit(4) -> 1, ...
+    assert nh[:, 0].tolist() == [0, 1, 2, 3, 1, 2]
+    assert (masks[3] == 0).all() and masks.sum() == (T - 1) * E
+    # stored (state, #rows) pairs reproduce the stored values through the dense-history predict()
+    t = 2
+    hist = np.zeros((E, R, S), np.float32); hist[:, :2] = st[t][:, None]
+    np.testing.assert_allclose(net.predict(st[t], hist)["vs"], vals[t], rtol=1e-6, atol=1e-5)
+    # tanh-transformed actions were legal (no GRL_E_ACTION_RANGE), returns follow the masked/clipped PAAC rule
+    y = net.read_rollout("y", (T, E)); adv = net.read_rollout("adv", (T, E))
+    oy, oadv = O.nstep_returns(O.rescale_reward(rews).astype(np.float64), vals, boot, 0.99, masks.astype(np.float64))
+    np.testing.assert_allclose(y, oy, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(adv, oadv / 100.0, rtol=1e-5, atol=1e-6)
+    # gradients on the rollout's samples equal the oracle's on the equivalent dense histories
+    stats = net.train_rollout(0.0)
+    hist_all = np.zeros((T * E, R, S))
+    flat_states = st.reshape(T * E, S).astype(np.float64)
+    rows = np.minimum(np.maximum(nh.reshape(-1), 1), R)
+    for r in range(R):
+        hist_all[:, r] = np.where((r < rows)[:, None], flat_states, 0.0)
+    loss, pl, cl, g, _ = NN.flat_loss_and_grads(p, flat_states, hist_all, acts.reshape(T * E, n).astype(np.float64),
+                                                adv.reshape(-1).astype(np.float64), y.reshape(-1).astype(np.float64), 100.0)
+    np.testing.assert_allclose(stats["loss"], loss, rtol=2e-4, atol=1e-6)
+    shapes = NN.flat_param_shapes(S, S, 32, 32, n)
+    got = NN.unflatten_params(net.get_grads().astype(np.float64), shapes)
+    for name, _ in shapes:
+        err = np.abs(got[name] - g[name]).max() / (np.abs(g[name]).max() + 1e-12)
+        assert err < 3e-4, (name, err)
