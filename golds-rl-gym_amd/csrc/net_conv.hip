@@ -54,6 +54,9 @@ struct grl_net {
     // gradients of activations (chunk)
     float *ga1, *ga2, *ga3, *gd1, *gd2, *gp1, *gv1, *gv2;
     float *w3t, *w2t;          // rearranged conv weights for the data gradients
+    // shared-trunk evaluation of conv1/conv2 (net_shared.inc): per-ENV tensors
+    int shared_trunk;
+    float *sraw, *a1sh, *z2sh, *dz2, *gt;
     float *slab;               // split-M partial sums
     size_t slab_floats;
     double *slab64;
@@ -138,7 +141,8 @@ static void refresh_transposes(grl_net *net) {
 // w = y-bin (np.histogram2d's first output axis is x; state_processors.py:31-33).
 __global__ __launch_bounds__(256) void conv1_sparse_kernel(const uint8_t *__restrict__ lbins, const uint8_t *__restrict__ abins,
                                                            const uint8_t *__restrict__ pos, const float *__restrict__ w1,
-                                                           const float *__restrict__ b1, float *__restrict__ a1, int G) {
+                                                           const float *__restrict__ b1, float *__restrict__ a1, int G,
+                                                           float *__restrict__ sraw, float *__restrict__ a1sh) {
     __shared__ unsigned int cnt[2][7056 / 4 + 4];   // 84x84 byte counters per channel, packed 4 per word
     __shared__ float S[400 * 32];                    // pre-activation shared by the env's 10 agents
     const int env = blockIdx.x, tid = threadIdx.x;
@@ -180,6 +184,16 @@ __global__ __launch_bounds__(256) void conv1_sparse_kernel(const uint8_t *__rest
         for (int co = 0; co < 32; ++co) S[pix * 32 + co] = acc[co];
     }
     __syncthreads();
+    if (sraw) {   // shared-trunk mode (net_shared.inc): one pre-activation and one relu image per ENV, no per-agent copies
+        float4 *o0 = reinterpret_cast<float4 *>(sraw + (size_t)env * 12800), *o1 = reinterpret_cast<float4 *>(a1sh + (size_t)env * 12800);
+        for (int i = tid; i < 3200; i += 256) {
+            float4 v = reinterpret_cast<const float4 *>(S)[i];
+            o0[i] = v;
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            o1[i] = v;
+        }
+        return;
+    }
     for (int a = 0; a < 10; ++a) {
         const int ph = pos[((size_t)env * 10 + a) * 2], pw = pos[((size_t)env * 10 + a) * 2 + 1];
         float4 *out = reinterpret_cast<float4 *>(a1 + ((size_t)env * 10 + a) * 12800);
@@ -248,6 +262,8 @@ __global__ void sample_actions_kernel(const float *__restrict__ mu, const float 
     reinterpret_cast<float2 *>(envact)[i] = r;
 }
 
+#include "net_shared.inc"
+
 // ------------------------------------------------------------------------------------------ forward pass of one chunk
 static int forward_chunk(grl_net *net, const uint8_t *lb, const uint8_t *ab, const uint8_t *pos, int nenv, float *mu,
                          float *sigma, float *vs) {
@@ -255,14 +271,19 @@ static int forward_chunk(grl_net *net, const uint8_t *lb, const uint8_t *ab, con
     const float *P = net->params, *PT = net->paramsT;
     const int n = nenv * 10;
     net->last_n = n;
+    if (net->shared_trunk) {
+        int rc = forward_conv12_shared(net, lb, ab, pos, nenv);
+        if (rc) return rc;
+    } else {
     hipLaunchKernelGGL(conv1_sparse_kernel, dim3(nenv), dim3(256), 0, st, lb, ab, pos, P + ConvOffsets::c1w, P + ConvOffsets::c1b,
-                       net->a1, net->h->cfg.grid_size);
+                       net->a1, net->h->cfg.grid_size, (float *)nullptr, (float *)nullptr);
     {
         GatherConv2 g{net->a1, n * 81};
         EpiBiasAct e{net->a2, 64, P + ConvOffsets::c2b, ACT_RELU};
         GemmTimer t(net, 2.0 * n * 81 * 512 * 64);
         hipLaunchKernelGGL((gemm_rowk<256, 64, 4, 1, GatherConv2, EpiBiasAct>), dim3((n * 81 + 255) / 256, 1), dim3(256), 0, st,
                            g, PT + ConvOffsets::c2w, 512, 64, e);
+    }
     }
     {
         GatherConv3 g{net->a2, n * 49};
@@ -356,6 +377,8 @@ int grl_net_create(grl_handle *h, const grl_net_config *cfg, grl_net **out) {
     A(&n->params, ConvOffsets::total); A(&n->paramsT, ConvOffsets::total); A(&n->grads, ConvOffsets::total); A(&n->adam_m, ConvOffsets::total); A(&n->adam_v, ConvOffsets::total);
     A(&n->a1, c * 12800); A(&n->a2, c * 5184); A(&n->a3, c * 3136); A(&n->d1, c * 512); A(&n->d2, c * 256);
     A(&n->p1, c * 512); A(&n->v1, c * 512); A(&n->v2, c * 256); A(&n->stats, 16);
+    n->shared_trunk = (cfg->reserved & 1) ? 0 : 1;     // GRL_NET_F_PER_AGENT_TRUNK: the plain per-agent evaluation (A/B reference)
+    A(&n->sraw, (c / 10) * 12800); A(&n->a1sh, (c / 10) * 12800); A(&n->z2sh, (c / 10) * 5184);
     if (rc == GRL_OK) rc = ensure_tmp_obs(n, h->E);
     if (rc != GRL_OK) {
         fail(h, rc, "grl_net_create: " + n->err);
@@ -440,7 +463,17 @@ int grl_net_read_activation(grl_net *n, const char *which, float *host, size_t b
     std::string w(which);
     const float *src = nullptr;
     size_t per = 0;
-    if (w == "a1") { src = n->a1; per = 12800; }
+    if (w == "a1") {
+        if (n->shared_trunk) return nfail(n, GRL_E_INVALID, "grl_net_read_activation: 'a1' is not materialised in shared-trunk mode (read 'a1sh')");
+        src = n->a1; per = 12800;
+    }
+    else if (w == "a1sh" || w == "sraw") {     // per ENV: (n/10, 20, 20, 32)
+        size_t need_e = (size_t)(n->last_n / 10) * 12800 * 4;
+        if (bytes != need_e) return nfail(n, GRL_E_SIZE, "grl_net_read_activation: need " + std::to_string(need_e) + " bytes");
+        NET_HIP(n, hipStreamSynchronize(n->h->stream));
+        NET_HIP(n, hipMemcpy(host, w == "a1sh" ? n->a1sh : n->sraw, bytes, hipMemcpyDeviceToHost));
+        return GRL_OK;
+    }
     else if (w == "a2") { src = n->a2; per = 5184; }
     else if (w == "a3") { src = n->a3; per = 3136; }
     else if (w == "d1") { src = n->d1; per = 512; }

@@ -113,7 +113,7 @@ struct EpiGradStride2 {
         int yh = q / 10, xh = q - yh * 10;
         int cls = col >> 5, c = col & 31;
         long i = (((long)n * 20 + 2 * yh + (cls >> 1)) * 20 + 2 * xh + (cls & 1)) * 32 + c;
-        dX[i] = fwd[i] > 0.f ? v : 0.f;
+        dX[i] = fwd ? (fwd[i] > 0.f ? v : 0.f) : v;     // fwd == nullptr: raw transposed convolution (shared-trunk mode)
     }
 };
 

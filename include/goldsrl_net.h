@@ -21,12 +21,15 @@ extern "C" {
 #endif
 
 #define GRL_NET_CONV_SINGLE_AGENT 0 /* policy_v_network.py:5-66; Swarm handles only */
+/* Evaluate conv1/conv2 per agent image instead of once per env + exact per-agent corrections (the default,
+ * csrc/net_shared.inc).  Same sums, different association; kept as the A/B reference of the optimisation. */
+#define GRL_NET_F_PER_AGENT_TRUNK 0x1
 
 typedef struct grl_net_config {
     int32_t struct_size;
     int32_t kind;              /* GRL_NET_* */
     int32_t max_chunk_samples; /* agent-samples processed per pass; activations are sized for this (multiple of 10) */
-    int32_t reserved;
+    int32_t reserved;          /* flags: GRL_NET_F_* */
     float scale;               /* conf['scale'] (train_paac_conv.py --scale, 1000) */
     float entropy_beta;        /* conf['entropy_regularisation_strength'] (0.02) */
     float clip_norm;           /* --clip_norm (40), clip_norm_type 'global'; <= 0 means 'ignore' */
@@ -74,7 +77,8 @@ int grl_net_train_obs(grl_net *net, int32_t n_envs, const uint8_t *locust_bins, 
  * "rewards" (T,B), "y" (T,B), "adv" (T,B), "boot" (B,). */
 int grl_net_read_rollout(grl_net *net, const char *which, void *host, size_t bytes);
 /* Debug/test access to a forward activation of the last chunk: "a1" (n,20,20,32) "a2" (n,9,9,64)
- * "a3" (n,7,7,64) "d1" (n,512) "d2" (n,256) "p1" (n,512) "v1" (n,512) "v2" (n,256). */
+ * "a3" (n,7,7,64) "d1" (n,512) "d2" (n,256) "p1" (n,512) "v1" (n,512) "v2" (n,256); "a1" only with
+ * GRL_NET_F_PER_AGENT_TRUNK, otherwise the per-env "a1sh"/"sraw" (n/10,20,20,32). */
 int grl_net_read_activation(grl_net *net, const char *which, float *host, size_t bytes);
 
 /* ---- multi-GPU: one process per GPU, one RCCL all-reduce (sum, fp32) of the flat gradient per

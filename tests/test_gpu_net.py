@@ -10,14 +10,14 @@ from oracle import oracle as O
 pytestmark = pytest.mark.gpu
 
 
-def _setup(E, seed=0, biased=True):
+def _setup(E, seed=0, biased=True, flags=0):
     from goldsrl import _ffi, _ffi_net
     eng = _ffi.Engine(_ffi.ENV_SWARM, E, seed=11)
     eng.reset()
     rng = np.random.RandomState(seed)
     for _ in range(3):
         eng.step(O.swarm_transform_actions(rng.normal(size=(E, 10, 2)).astype(np.float32)))
-    net = _ffi_net.ConvNet(eng, max_chunk_samples=40)
+    net = _ffi_net.ConvNet(eng, max_chunk_samples=40, reserved=flags)
     flat = _ffi_net.glorot_uniform_flat(seed=3).astype(np.float64)
     p = NN.unflatten_params(flat)
     if biased:
@@ -43,15 +43,21 @@ def test_param_vector_layout():
     assert _ffi_net.glorot_uniform_flat().size == 2210213
 
 
-def test_conv_forward_matches_oracle_layer_by_layer():
+@pytest.mark.parametrize("flags", [0, 1])      # 0: shared-trunk conv1/conv2 (default), 1: plain per-agent evaluation
+def test_conv_forward_matches_oracle_layer_by_layer(flags):
     E = 6    # 60 samples: two chunks of 40 -> exercises chunking and partial tiles
-    eng, net, p, states, obs = _setup(E)
+    eng, net, p, states, obs = _setup(E, flags=flags)
     out = net.predict()
     mu, sigma, vs, c = NN.conv_forward(p, states, 1000.0, keep=True)
     # activations of the LAST chunk (envs 4,5 -> samples 40..59)
     n_last = 20
-    for name, ref in (("a1", c["a1"]), ("a2", c["a2"]), ("a3", c["a3"]), ("d1", c["d1"]), ("d2", c["d2"]), ("p1", c["p1"]),
-                      ("v1", c["v1"]), ("v2", c["v2"])):
+    if flags == 0:     # per-env shared conv1 image = conv1 of the image without its one-hot channel
+        sh = states[40::10].copy(); sh[..., 2] = 0
+        z1, _ = NN._conv(sh, p["conv1_w"], p["conv1_b"], 4)
+        np.testing.assert_allclose(net.read_activation("sraw", z1.shape), z1, rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(net.read_activation("a1sh", z1.shape), np.maximum(z1, 0), rtol=2e-5, atol=2e-6)
+    for name, ref in ((("a1", c["a1"]),) if flags else ()) + (("a2", c["a2"]), ("a3", c["a3"]), ("d1", c["d1"]), ("d2", c["d2"]),
+                                                              ("p1", c["p1"]), ("v1", c["v1"]), ("v2", c["v2"])):
         ref = ref[40:]
         got = net.read_activation(name, ref.shape)
         np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-6, err_msg=name)
@@ -79,9 +85,10 @@ def _train_inputs(E, seed=1):
         (-rng.rand(n) * 400).astype(np.float32)
 
 
-def test_conv_gradients_match_oracle():
+@pytest.mark.parametrize("flags", [0, 1])
+def test_conv_gradients_match_oracle(flags):
     E = 6      # 60 samples, chunk 40: gradients accumulate over two chunks
-    eng, net, p, states, obs = _setup(E)
+    eng, net, p, states, obs = _setup(E, flags=flags)
     act, adv, y = _train_inputs(E)
     stats = net.train_obs(*obs, act, adv, y, lr=0.0, apply_update=False)
     loss, pl, cl, g, _ = NN.conv_loss_and_grads(p, states, act.astype(np.float64), adv.astype(np.float64), y.astype(np.float64), 0.02, 1000.0)
