@@ -37,6 +37,7 @@ using GatherConv2 = ConvGather<9, 9, 2, 2, 0, 0, 4, 4, 32, 20, 20, false>;    //
 using GatherConv3 = ConvGather<7, 7, 1, 1, 0, 0, 3, 3, 64, 9, 9, false>;      // a2[n][9][9][64]  -> (n*49, 576)
 // data gradients (transposed convolutions, zero-filled borders):
 using GatherT3 = ConvGather<9, 9, 1, 1, -2, -2, 3, 3, 64, 7, 7, true>;        // dz3[n][7][7][64] -> rows (n,y,x) of a2
+using GatherT3PM = ConvGatherPM<9, 9, -2, -2, 3, 3, 64, 7, 7>;               // same, pixel-major rows: border taps skipped
 using GatherT2 = ConvGather<10, 10, 1, 1, -1, -1, 2, 2, 64, 9, 9, true>;      // dz2[n][9][9][64] -> rows (n,yh,xh) per parity
 
 }  // namespace grl

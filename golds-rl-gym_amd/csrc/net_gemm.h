@@ -57,6 +57,40 @@ struct ConvGather {
     __device__ __forceinline__ bool ok(int iy0, int ix0, int ty, int tx) const {
         return !CHECK || ((unsigned)(iy0 + ty) < (unsigned)H && (unsigned)(ix0 + tx) < (unsigned)W);
     }
+    __device__ __forceinline__ bool tile_ok(int, int) const { return true; }
+};
+
+// Pixel-major variant for stride-1 transposed convolutions: row r = q*nsamp + n (pixel q of sample n), so when
+// nsamp is a multiple of the M tile every row of a workgroup is the SAME pixel and the validity of a tap is
+// block-uniform: K-tiles whose tap falls outside the image are skipped instead of multiplied by zeros
+// (conv3's data gradient: 441 of 729 (pixel, tap) combinations are inside).
+template <int QH, int QW, int OY0, int OX0, int S, int P, int C, int H, int W>
+struct ConvGatherPM {
+    const float *base;
+    int rows, nsamp;
+    __device__ __forceinline__ int K() const { return S * P * C; }
+    __device__ __forceinline__ void row(int r, long &off, int &iy0, int &ix0) const {
+        int q = r / nsamp, n = r - q * nsamp;
+        int qy = q / QW, qx = q - qy * QW;
+        iy0 = qy + OY0;
+        ix0 = qx + OX0;
+        off = (long)n * (H * W * C) + ((long)iy0 * W + ix0) * C;
+    }
+    __device__ __forceinline__ void tap(int k0, int &toff, int &ty, int &tx) const {
+        int t = k0 / C;
+        int c0 = k0 - t * C;
+        ty = t / P;
+        tx = t - ty * P;
+        toff = (ty * W + tx) * C + c0;
+    }
+    __device__ __forceinline__ bool ok(int iy0, int ix0, int ty, int tx) const {
+        return (unsigned)(iy0 + ty) < (unsigned)H && (unsigned)(ix0 + tx) < (unsigned)W;
+    }
+    __device__ __forceinline__ bool tile_ok(int m0, int k0) const {
+        int q = m0 / nsamp, qy = q / QW, qx = q - qy * QW;
+        int t = k0 / C, ty = t / P, tx = t - ty * P;
+        return ok(qy + OY0, qx + OX0, ty, tx);
+    }
 };
 
 struct DenseRows {   // plain row-major [rows][ld], reduction length k
@@ -72,6 +106,7 @@ struct DenseRows {   // plain row-major [rows][ld], reduction length k
         ty = tx = 0;
     }
     __device__ __forceinline__ bool ok(int, int, int, int) const { return true; }
+    __device__ __forceinline__ bool tile_ok(int, int) const { return true; }
 };
 
 // ---------------------------------------------------------------------------- epilogues
@@ -99,6 +134,17 @@ struct EpiGrad {   // dX[r][c] = (v [+ dX[r][c]]) * (fwd[r][c] > 0 if mask)
         if (accumulate) v += dX[i];
         if (fwd) v = fwd[i] > 0.f ? v : 0.f;
         dX[i] = v;
+    }
+};
+
+struct EpiGradPM {   // pixel-major rows (r = q*nsamp + n) -> dX[n][q][c], ReLU mask of the forward tensor fused
+    float *dX;
+    const float *fwd;
+    int nsamp, pps, ld;
+    __device__ __forceinline__ void operator()(int r, int c, float v) const {
+        int q = r / nsamp, n = r - q * nsamp;
+        long i = ((long)n * pps + q) * ld + c;
+        dX[i] = fwd[i] > 0.f ? v : 0.f;
     }
 };
 
@@ -193,16 +239,21 @@ __global__ __launch_bounds__(256, 2) void gemm_rowk(AG ag, const float *__restri
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     const int nk = K / BK;
-    GRL_LOAD_TILE(0)
+    // K-tiles whose tap is outside the image for the WHOLE workgroup are skipped (tile_ok is block-uniform)
+    int kt = 0;
+    while (kt < nk && !ag.tile_ok(m0, kt * BK)) ++kt;
+    GRL_LOAD_TILE(kt < nk ? kt : 0)
     const int lr = lane & 31, lk = lane >> 5;
     const float *ap = As + (wm * WM + lr) * LD + lk * 16;
     const float *bp = Bs + (wn * WN + lr) * LD + lk * 16;
-    for (int kt = 0; kt < nk; ++kt) {
+    while (kt < nk) {
         GRL_STORE_TILE()
         __syncthreads();
-        {   // prefetch the next K-tile (the last iteration re-reads its own tile: branch-free)
-            const int ktn = kt + 1 < nk ? kt + 1 : kt;
-            GRL_LOAD_TILE(ktn)
+        int ktn = kt + 1;
+        while (ktn < nk && !ag.tile_ok(m0, ktn * BK)) ++ktn;
+        {   // prefetch the next valid K-tile (the last iteration re-reads its own tile: branch-free)
+            const int ktl = ktn < nk ? ktn : kt;
+            GRL_LOAD_TILE(ktl)
         }
         __builtin_amdgcn_sched_barrier(0);   // keep every global load above the MFMA phase
 #pragma unroll
@@ -224,6 +275,7 @@ __global__ __launch_bounds__(256, 2) void gemm_rowk(AG ag, const float *__restri
         }
         __builtin_amdgcn_sched_barrier(0);   // ... and the LDS stores of the next tile below it
         __syncthreads();
+        kt = ktn;
     }
     // C/D map of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
