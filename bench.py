@@ -95,7 +95,7 @@ def _cpu_cores():
     return min(ncores, 32)
 
 
-def cpu_baseline(sample_envs, T, full_update_envs=4):
+def cpu_baseline(sample_envs, T, full_update_envs=16):
     """CPU baseline from the oracle ("port"), bounded sample of the SAME workload: a full PAAC update
     (dense 84x84x3 images as the reference builds them, conv policy forward per step, C env step + observation,
     n-step returns, loss + backward over the T*E*10 samples) on `full_update_envs` envs; numpy/BLAS threads +

@@ -176,7 +176,9 @@ __global__ __launch_bounds__(256, 2) void gemm_rowk(AG ag, const float *__restri
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave - wm * WGN;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    // N tiles vary fastest in launch order: the workgroups that share one A tile run together, so it is
+    // fetched from HBM once and served to the others by L2 (the B operand is small and always cached)
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int M = ag.rows, K = ag.K();
     const int trow = tid >> 3, tk4 = (tid & 7) * 4;
 

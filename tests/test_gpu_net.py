@@ -203,3 +203,24 @@ def test_gradient_paths_agree_at_tile_multiple_sizes():
     for s in stats[:2]:
         np.testing.assert_allclose(s["loss"], stats[2]["loss"], rtol=1e-5)
         np.testing.assert_allclose(s["global_norm"], stats[2]["global_norm"], rtol=1e-5)
+
+
+def test_rccl_communicator_world_size_1():
+    """The RCCL path (unique id -> ncclCommInitRank -> broadcast params -> all-reduce inside train) on one GPU:
+    with world_size 1 the all-reduce is the identity and grad_scale is 1, so results must equal the no-comm run."""
+    from goldsrl import _ffi, _ffi_net
+    E = 4
+    eng, net, p, states, obs = _setup(E)
+    act, adv, y = _train_inputs(E)
+    ref = net.train_obs(*obs, act, adv, y, lr=0.0, apply_update=False)
+    g_ref = net.get_grads()
+    uid = net.comm_unique_id()
+    assert uid.size == int(net.lib.grl_comm_unique_id_bytes()) and uid.any()
+    net.comm_init(uid, 0, 1)
+    net.comm_broadcast_params(0)
+    got = net.train_obs(*obs, act, adv, y, lr=0.0, apply_update=False)
+    assert np.array_equal(net.get_grads(), g_ref)
+    assert got == ref
+    with pytest.raises(_ffi.GrlError) as ei:
+        net.comm_init(uid, 0, 1)
+    assert ei.value.code == _ffi.E_STATE
