@@ -78,6 +78,15 @@ struct grl_net {
     int last_n;                // samples in the last chunk (for read_activation)
     void *comm;                // ncclComm_t (RCCL) for the per-rollout gradient all-reduce, or nullptr
     int comm_world, comm_rank;
+    // Rollout-resident activations: the rollout's forward pass writes a3..v2 of every (step, chunk) into one
+    // T*B-sample buffer (20.7 KB per agent-sample, 136 GB at 32 768 envs x 20 steps -- what 288 GB of HBM is for) and
+    // the gradient step reads them back instead of recomputing conv3 and the dense stack.  Exact: parameters do
+    // not change between the two (paac.py:302-387).  keep_version tracks that; GRL_NET_F_RECOMPUTE_FORWARD or too
+    // little free memory selects recomputation.
+    float *ws_a3, *ws_d1, *ws_d2, *ws_p1, *ws_v1, *ws_v2;   // chunk workspace (the default binding of a3..v2)
+    float *keep;
+    size_t keep_slots;
+    long param_version, keep_version;
 };
 
 namespace grl {
@@ -266,8 +275,28 @@ __global__ void sample_actions_kernel(const float *__restrict__ mu, const float 
 #include "net_shared.inc"
 
 // ------------------------------------------------------------------------------------------ forward pass of one chunk
+static constexpr size_t KEEP_FLOATS_PER_SAMPLE = 3136 + 512 + 256 + 512 + 512 + 256;
+
+// a3..v2 point into slot `slot` of the rollout-resident buffer, or at the chunk workspace for slot < 0
+static void bind_activations(grl_net *net, long slot) {
+    if (slot < 0 || !net->keep) {
+        net->a3 = net->ws_a3; net->d1 = net->ws_d1; net->d2 = net->ws_d2; net->p1 = net->ws_p1; net->v1 = net->ws_v1; net->v2 = net->ws_v2;
+        return;
+    }
+    const size_t c = net->chunk;
+    float *b = net->keep + (size_t)slot * c * KEEP_FLOATS_PER_SAMPLE;
+    net->a3 = b; b += c * 3136;
+    net->d1 = b; b += c * 512;
+    net->d2 = b; b += c * 256;
+    net->p1 = b; b += c * 512;
+    net->v1 = b; b += c * 512;
+    net->v2 = b;
+}
+
+// reuse_tail: a3..v2 of this chunk are already resident (bind_activations); only the cheap per-env trunk, the
+// per-agent a2 and the heads are re-evaluated
 static int forward_chunk(grl_net *net, const uint8_t *lb, const uint8_t *ab, const uint8_t *pos, int nenv, float *mu,
-                         float *sigma, float *vs) {
+                         float *sigma, float *vs, bool reuse_tail = false) {
     hipStream_t st = net->h->stream;
     const float *P = net->params, *PT = net->paramsT;
     const int n = nenv * 10;
@@ -286,6 +315,7 @@ static int forward_chunk(grl_net *net, const uint8_t *lb, const uint8_t *ab, con
                            g, PT + ConvOffsets::c2w, 512, 64, e);
     }
     }
+    if (!reuse_tail) {
     {
         GatherConv3 g{net->a2, n * 49};
         EpiBiasAct e{net->a3, 64, P + ConvOffsets::c3b, ACT_RELU};
@@ -305,6 +335,7 @@ static int forward_chunk(grl_net *net, const uint8_t *lb, const uint8_t *ab, con
     dense(net->d2, 256, PT + ConvOffsets::p1w, P + ConvOffsets::p1b, 512, net->p1);
     dense(net->d2, 256, PT + ConvOffsets::v1w, P + ConvOffsets::v1b, 512, net->v1);
     dense(net->v1, 512, PT + ConvOffsets::v2w, P + ConvOffsets::v2b, 256, net->v2);
+    }
     hipLaunchKernelGGL(heads_forward_kernel, dim3((n + 3) / 4), dim3(256), 0, st, net->p1, net->v2, P, n, net->cfg.scale, mu, sigma, vs);
     NET_HIP(net, hipGetLastError());
     return GRL_OK;
@@ -312,10 +343,11 @@ static int forward_chunk(grl_net *net, const uint8_t *lb, const uint8_t *ab, con
 
 // forward over n_envs envs in chunks; obs pointers are DEVICE pointers; outputs device (B,2)(B,2)(B)
 static int forward_all(grl_net *net, const uint8_t *lb, const uint8_t *ab, const uint8_t *pos, int n_envs, float *mu, float *sigma,
-                       float *vs) {
+                       float *vs, long slot0 = -1) {
     const int ce = net->chunk / 10;
     for (int e0 = 0; e0 < n_envs; e0 += ce) {
         int ne = n_envs - e0 < ce ? n_envs - e0 : ce;
+        bind_activations(net, slot0 < 0 ? -1 : slot0 + e0 / ce);
         int rc = forward_chunk(net, lb + (size_t)e0 * 160, ab + (size_t)e0 * 20, pos + (size_t)e0 * 20, ne, mu + (size_t)e0 * 20,
                                sigma + (size_t)e0 * 20, vs + (size_t)e0 * 10);
         if (rc) return rc;
@@ -372,12 +404,14 @@ int grl_net_create(grl_handle *h, const grl_net_config *cfg, grl_net **out) {
     n->T = 0; n->B = 0; n->tmp_envs = 0; n->act_counter = 0; n->prof_on = false; n->prof_used = 0; n->prof_flops = 0; n->last_n = 0;
     n->ro_lb = nullptr; n->slab = nullptr; n->slab_floats = 0; n->slab64 = nullptr; n->w3t = n->w2t = nullptr;
     n->ga1 = nullptr; n->mu = n->sigma = n->vs = nullptr;
+    n->keep = nullptr; n->keep_slots = 0; n->param_version = 0; n->keep_version = -1;
     size_t c = n->chunk;
     int rc = GRL_OK;
     auto A = [&](float **p, size_t cnt) { if (rc == GRL_OK) rc = nalloc(n, p, cnt); };
     A(&n->params, ConvOffsets::total); A(&n->paramsT, ConvOffsets::total); A(&n->grads, ConvOffsets::total); A(&n->adam_m, ConvOffsets::total); A(&n->adam_v, ConvOffsets::total);
     A(&n->a1, c * 12800); A(&n->a2, c * 5184); A(&n->a3, c * 3136); A(&n->d1, c * 512); A(&n->d2, c * 256);
     A(&n->p1, c * 512); A(&n->v1, c * 512); A(&n->v2, c * 256); A(&n->stats, 16);
+    n->ws_a3 = n->a3; n->ws_d1 = n->d1; n->ws_d2 = n->d2; n->ws_p1 = n->p1; n->ws_v1 = n->v1; n->ws_v2 = n->v2;
     n->shared_trunk = (cfg->reserved & 1) ? 0 : 1;     // GRL_NET_F_PER_AGENT_TRUNK: the plain per-agent evaluation (A/B reference)
     A(&n->sraw, (c / 10) * 12800); A(&n->a1sh, (c / 10) * 12800); A(&n->z2sh, (c / 10) * 5184);
     if (rc == GRL_OK) rc = ensure_tmp_obs(n, h->E);
@@ -397,6 +431,7 @@ int grl_net_destroy(grl_net *n) {
     hipStreamSynchronize(n->h->stream);
     if (n->comm) ncclCommDestroy((ncclComm_t)n->comm);
     for (void *p : n->allocs) hipFree(p);
+    if (n->keep) hipFree(n->keep);
     for (hipEvent_t ev : n->prof_ev) hipEventDestroy(ev);
     delete n;
     return GRL_OK;
@@ -411,6 +446,7 @@ int grl_net_set_params(grl_net *n, const float *host, int64_t cnt) {
     hipSetDevice(n->h->cfg.device_id);
     NET_HIP(n, hipStreamSynchronize(n->h->stream));
     NET_HIP(n, hipMemcpy(n->params, host, cnt * 4, hipMemcpyHostToDevice));
+    n->param_version += 1;
     refresh_transposes(n);
     NET_HIP(n, hipStreamSynchronize(n->h->stream));
     return GRL_OK;

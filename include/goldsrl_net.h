@@ -24,6 +24,9 @@ extern "C" {
 /* Evaluate conv1/conv2 per agent image instead of once per env + exact per-agent corrections (the default,
  * csrc/net_shared.inc).  Same sums, different association; kept as the A/B reference of the optimisation. */
 #define GRL_NET_F_PER_AGENT_TRUNK 0x1
+/* Recompute conv3 and the dense stack in the gradient step instead of keeping the rollout's activations resident
+ * in HBM (20.7 KB per agent-sample and step; chosen automatically when that buffer does not fit).  Bit-identical. */
+#define GRL_NET_F_RECOMPUTE_FORWARD 0x2
 
 typedef struct grl_net_config {
     int32_t struct_size;

@@ -224,3 +224,29 @@ def test_rccl_communicator_world_size_1():
     with pytest.raises(_ffi.GrlError) as ei:
         net.comm_init(uid, 0, 1)
     assert ei.value.code == _ffi.E_STATE
+
+
+def test_resident_rollout_activations_equal_recomputation():
+    """The gradient step reads conv3/dense activations kept from the rollout's forward pass (default) or recomputes
+    them (GRL_NET_F_RECOMPUTE_FORWARD = 2): same kernels on the same inputs, so gradients are bit-identical.  The
+    second update checks that the kept activations are refreshed after the parameters moved."""
+    out = []
+    for flags in (0, 2):
+        eng, net, p, states, obs = _setup(12, flags=flags)       # 120 samples, chunks of 40 -> 3 slots per step
+        res = []
+        for _ in range(2):
+            net.rollout(3, 0)
+            eng.wait()
+            st = net.train_rollout(1e-3)
+            res.append((net.get_grads().copy(), net.get_params().copy(), st))
+        # a parameter upload between rollout and train invalidates the kept activations (falls back to recompute)
+        net.rollout(2, 0)
+        eng.wait()
+        net.set_params(net.get_params() * np.float32(1.01))
+        net.train_rollout(1e-3)
+        res.append((net.get_grads().copy(), net.get_params().copy(), None))
+        out.append(res)
+    for (g0, p0, s0), (g1, p1, s1) in zip(*out):
+        assert np.array_equal(g0, g1) and np.array_equal(p0, p1)
+        assert s0 == s1
+    assert np.abs(out[0][0][0]).max() > 0
