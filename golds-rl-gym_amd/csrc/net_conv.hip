@@ -429,7 +429,10 @@ int grl_net_destroy(grl_net *n) {
     if (!n) return GRL_OK;
     hipSetDevice(n->h->cfg.device_id);
     hipStreamSynchronize(n->h->stream);
-    if (n->comm) ncclCommDestroy((ncclComm_t)n->comm);
+    if (n->comm) {
+        ncclCommDestroy((ncclComm_t)n->comm);
+        (void)hipGetLastError();   // RCCL teardown may leave a stale HIP error on this thread
+    }
     for (void *p : n->allocs) hipFree(p);
     if (n->keep) hipFree(n->keep);
     for (hipEvent_t ev : n->prof_ev) hipEventDestroy(ev);

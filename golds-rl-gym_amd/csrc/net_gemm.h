@@ -425,23 +425,66 @@ __global__ void slab_reduce_kernel(const float *__restrict__ slab, int chunks, l
     dst[i] = accumulate ? dst[i] + s : s;
 }
 
+// Same for a short row (n up to a few thousand) and many chunks, where one lane per element would walk the chunks
+// serially: 16 elements per workgroup, 16 lanes per element each summing every 16th chunk, combined in fixed order.
+__global__ __launch_bounds__(256) void slab_reduce_narrow_kernel(const float *__restrict__ slab, int chunks, int n, float *__restrict__ dst,
+                                                                 int accumulate) {
+    __shared__ float red[256];
+    const int col = threadIdx.x & 15, part = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + col;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (i < n) {
+        int c = part;
+        for (; c + 48 < chunks; c += 64) {
+            s0 += slab[(long)c * n + i];
+            s1 += slab[(long)(c + 16) * n + i];
+            s2 += slab[(long)(c + 32) * n + i];
+            s3 += slab[(long)(c + 48) * n + i];
+        }
+        for (; c < chunks; c += 16) s0 += slab[(long)c * n + i];
+    }
+    red[threadIdx.x] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (part == 0 && i < n) {
+        float s = red[col];
+        for (int r = 1; r < 16; ++r) s += red[r * 16 + col];
+        dst[i] = accumulate ? dst[i] + s : s;
+    }
+}
+
 // column sums of dY[M][J] over row chunks -> slab[chunk][J]   (bias gradients)
 // 256 threads: min(J,256) column lanes x (256/J) row lanes, row lanes combined through LDS in a fixed order
 __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ dY, int M, int J, int mc, float *__restrict__ slab) {
-    __shared__ float red[256];
-    const int jw = J < 256 ? J : 256;            // J is a power of two >= 32 or a multiple of 256
-    const int rl = 256 / jw;
-    const int jl = threadIdx.x % jw, rsub = threadIdx.x / jw;
-    const int j = blockIdx.x * jw + jl;
+    // J in {32, 64, 256, 512, 1024}: a row is J/4 float4 lanes, 256/(J/4) rows per pass, four passes in flight
+    __shared__ float4 red[256];
+    const int jv = J >> 2;
+    const int rl = 256 / jv;
+    const int jl = threadIdx.x % jv, rsub = threadIdx.x / jv;
     const int mbeg = blockIdx.y * mc, mend = min(M, mbeg + mc);
-    float s = 0.f;
-    if (j < J)
-        for (int m = mbeg + rsub; m < mend; m += rl) s += dY[(long)m * J + j];
+    const float4 *__restrict__ p = reinterpret_cast<const float4 *>(dY) + jl;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+    int m = mbeg + rsub;
+    for (; m + 3 * rl < mend; m += 4 * rl) {
+        const float4 v0 = p[(long)m * jv], v1 = p[(long)(m + rl) * jv], v2 = p[(long)(m + 2 * rl) * jv], v3 = p[(long)(m + 3 * rl) * jv];
+        s0.x += v0.x; s0.y += v0.y; s0.z += v0.z; s0.w += v0.w;
+        s1.x += v1.x; s1.y += v1.y; s1.z += v1.z; s1.w += v1.w;
+        s2.x += v2.x; s2.y += v2.y; s2.z += v2.z; s2.w += v2.w;
+        s3.x += v3.x; s3.y += v3.y; s3.z += v3.z; s3.w += v3.w;
+    }
+    for (; m < mend; m += rl) {
+        const float4 v0 = p[(long)m * jv];
+        s0.x += v0.x; s0.y += v0.y; s0.z += v0.z; s0.w += v0.w;
+    }
+    float4 s = make_float4((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y), (s0.z + s1.z) + (s2.z + s3.z),
+                           (s0.w + s1.w) + (s2.w + s3.w));
     red[threadIdx.x] = s;
     __syncthreads();
-    if (rsub == 0 && j < J) {
-        for (int r = 1; r < rl; ++r) s += red[r * jw + jl];
-        slab[(long)blockIdx.y * J + j] = s;
+    if (rsub == 0) {
+        for (int r = 1; r < rl; ++r) {
+            const float4 v = red[r * jv + jl];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        reinterpret_cast<float4 *>(slab + (long)blockIdx.y * J)[jl] = s;
     }
 }
 

@@ -228,7 +228,7 @@ def test_rccl_communicator_world_size_1():
 
 def test_resident_rollout_activations_equal_recomputation():
     """The gradient step reads conv3/dense activations kept from the rollout's forward pass (default) or recomputes
-    them (GRL_NET_F_RECOMPUTE_FORWARD = 2): same kernels on the same inputs, so gradients are bit-identical.  The
+    them (GRL_NET_F_RECOMPUTE_FORWARD = 2): same kernels on the same inputs.  The
     second update checks that the kept activations are refreshed after the parameters moved."""
     out = []
     for flags in (0, 2):
@@ -246,7 +246,12 @@ def test_resident_rollout_activations_equal_recomputation():
         net.train_rollout(1e-3)
         res.append((net.get_grads().copy(), net.get_params().copy(), None))
         out.append(res)
+    # everything but conv1_w (first 6144 entries: its sparse weight gradient accumulates with fp64 LDS atomics, so the
+    # last float bit may depend on arrival order) is bit-identical on the first update
+    assert np.array_equal(out[0][0][0][6144:], out[1][0][0][6144:])
     for (g0, p0, s0), (g1, p1, s1) in zip(*out):
-        assert np.array_equal(g0, g1) and np.array_equal(p0, p1)
-        assert s0 == s1
+        np.testing.assert_allclose(g0, g1, rtol=2e-5, atol=1e-9)
+        np.testing.assert_allclose(p0, p1, rtol=2e-5, atol=1e-7)
+        if s0 is not None:
+            np.testing.assert_allclose(list(s0.values()), list(s1.values()), rtol=1e-6)
     assert np.abs(out[0][0][0]).max() > 0
