@@ -58,6 +58,10 @@ struct grl_net {
     // shared-trunk evaluation of conv1/conv2 (net_shared.inc): per-ENV tensors
     int shared_trunk;
     float *sraw, *a1sh, *z2sh, *dz2, *gt;
+    // shared conv3 gradients: per-env a2sh = relu(z2sh), DZ3; per (agent, slot <= 9 touched conv2 pixels): pixel id,
+    // a2_a[u], a2_a[u] - a2sh[u], T3(dz3_a)[u], masked dz2_a[u]; tmpw3: correction GEMM output before the tap flip
+    float *a2sh, *d2s, *v2s, *gsl, *dza, *dz3sh, *tmpw3;
+    signed char *ulist;
     float *slab;               // split-M partial sums
     size_t slab_floats;
     double *slab64;
@@ -302,7 +306,7 @@ static int forward_chunk(grl_net *net, const uint8_t *lb, const uint8_t *ab, con
     const int n = nenv * 10;
     net->last_n = n;
     if (net->shared_trunk) {
-        int rc = forward_conv12_shared(net, lb, ab, pos, nenv);
+        int rc = forward_conv12_shared(net, lb, ab, pos, nenv, !reuse_tail);
         if (rc) return rc;
     } else {
     hipLaunchKernelGGL(conv1_sparse_kernel, dim3(nenv), dim3(256), 0, st, lb, ab, pos, P + ConvOffsets::c1w, P + ConvOffsets::c1b,
@@ -414,6 +418,8 @@ int grl_net_create(grl_handle *h, const grl_net_config *cfg, grl_net **out) {
     n->ws_a3 = n->a3; n->ws_d1 = n->d1; n->ws_d2 = n->d2; n->ws_p1 = n->p1; n->ws_v1 = n->v1; n->ws_v2 = n->v2;
     n->shared_trunk = (cfg->reserved & 1) ? 0 : 1;     // GRL_NET_F_PER_AGENT_TRUNK: the plain per-agent evaluation (A/B reference)
     A(&n->sraw, (c / 10) * 12800); A(&n->a1sh, (c / 10) * 12800); A(&n->z2sh, (c / 10) * 5184);
+    A(&n->a2sh, (c / 10) * 5184); A(&n->d2s, c * 9 * 64); A(&n->v2s, c * 9 * 64);
+    if (rc == GRL_OK) rc = nalloc(n, &n->ulist, c * 9);
     if (rc == GRL_OK) rc = ensure_tmp_obs(n, h->E);
     if (rc != GRL_OK) {
         fail(h, rc, "grl_net_create: " + n->err);

@@ -93,6 +93,34 @@ struct ConvGatherPM {
     }
 };
 
+// conv3's transposed convolution evaluated only at the <= 9 conv2 pixels an agent's one-hot can reach:
+// row r = (sample n = r/9, slot r%9) with pixel u = ulist[r] of the 9x9 map (or -1: empty slot, all taps invalid);
+// k = (ty, tx, co) reads dz3[n][uy-2+ty][ux-2+tx][co] like ConvGather<9,9,1,1,-2,-2,3,3,64,7,7,true>.
+struct SlotGatherT3 {
+    const float *base;
+    const signed char *ulist;
+    int rows;
+    __device__ __forceinline__ int K() const { return 576; }
+    __device__ __forceinline__ void row(int r, long &off, int &iy0, int &ix0) const {
+        const int n = r / 9, u = ulist[r];
+        const int qy = u / 9, qx = u - qy * 9;
+        iy0 = u < 0 ? -16 : qy - 2;
+        ix0 = u < 0 ? -16 : qx - 2;
+        off = (long)n * (49 * 64) + ((long)iy0 * 7 + ix0) * 64;
+    }
+    __device__ __forceinline__ void tap(int k0, int &toff, int &ty, int &tx) const {
+        int t = k0 >> 6;
+        int c0 = k0 & 63;
+        ty = t / 3;
+        tx = t - ty * 3;
+        toff = (ty * 7 + tx) * 64 + c0;
+    }
+    __device__ __forceinline__ bool ok(int iy0, int ix0, int ty, int tx) const {
+        return (unsigned)(iy0 + ty) < 7u && (unsigned)(ix0 + tx) < 7u;
+    }
+    __device__ __forceinline__ bool tile_ok(int, int) const { return true; }
+};
+
 struct DenseRows {   // plain row-major [rows][ld], reduction length k
     const float *base;
     int rows, ld, k;

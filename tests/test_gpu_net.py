@@ -172,11 +172,12 @@ def test_device_rollout_matches_oracle_pieces():
 
 
 def test_gradient_paths_agree_at_tile_multiple_sizes():
-    """1280 samples per chunk (a multiple of the 256-row tile) enables the pixel-major conv3 data gradient with
-    skipped border taps; 640 uses the zero-filled form; flags=1 the plain per-agent conv1/conv2.  Same sums,
-    different association: all three gradients must agree to float32 round-off."""
+    """Row counts that are a multiple of the 256-row tile enable the pixel-major conv3 data gradient with skipped
+    border taps (256 envs per chunk in shared-trunk mode, 1280 samples per chunk in per-agent mode); the other
+    sizes use the zero-filled form; flags=1 is the plain per-agent conv1/conv2/conv3.  Same sums, different
+    association: all gradients must agree to float32 round-off."""
     from goldsrl import _ffi, _ffi_net
-    E = 128
+    E = 256
     eng = _ffi.Engine(_ffi.ENV_SWARM, E, seed=21)
     eng.reset()
     rng = np.random.RandomState(0)
@@ -187,22 +188,22 @@ def test_gradient_paths_agree_at_tile_multiple_sizes():
     flat = flat + (rng.normal(size=flat.size) * 0.01).astype(np.float32)
     act, adv, y = _train_inputs(E, seed=5)
     grads, stats = [], []
-    for chunk, flags in ((1280, 0), (640, 0), (640, 1)):
+    for chunk, flags in ((2560, 0), (1280, 0), (1280, 1), (640, 1)):
         net = _ffi_net.ConvNet(eng, max_chunk_samples=chunk, reserved=flags)
         net.set_params(flat)
         stats.append(net.train_obs(*obs, act, adv, y, lr=0.0, apply_update=False))
         grads.append(net.get_grads().astype(np.float64))
         net.close()
     shapes = NN.CONV_PARAM_SHAPES
-    ref = NN.unflatten_params(grads[2], shapes)
-    for g in grads[:2]:
+    ref = NN.unflatten_params(grads[3], shapes)
+    for g in grads[:3]:
         got = NN.unflatten_params(g, shapes)
         for name, _ in shapes:
             err = np.abs(got[name] - ref[name]).max() / (np.abs(ref[name]).max() + 1e-12)
             assert err < 5e-5, (name, err)
-    for s in stats[:2]:
-        np.testing.assert_allclose(s["loss"], stats[2]["loss"], rtol=1e-5)
-        np.testing.assert_allclose(s["global_norm"], stats[2]["global_norm"], rtol=1e-5)
+    for s in stats[:3]:
+        np.testing.assert_allclose(s["loss"], stats[3]["loss"], rtol=1e-5)
+        np.testing.assert_allclose(s["global_norm"], stats[3]["global_norm"], rtol=1e-5)
 
 
 def test_rccl_communicator_world_size_1():
