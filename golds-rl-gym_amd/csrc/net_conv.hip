@@ -61,6 +61,10 @@ struct grl_net {
     // shared conv3 gradients: per-env a2sh = relu(z2sh), DZ3; per (agent, slot <= 9 touched conv2 pixels): pixel id,
     // a2_a[u], a2_a[u] - a2sh[u], T3(dz3_a)[u], masked dz2_a[u]; tmpw3: correction GEMM output before the tap flip
     float *a2sh, *d2s, *v2s, *gsl, *dza, *dz3sh, *tmpw3;
+    // shared conv3 forward: z3sh = conv3(a2sh) + b3 per env, w3f[(tap,co)][ci] = W3[tap][ci][co]; the per-slot products
+    // (a2_a - a2sh)[u] . W3[tap] (n*9 x 576) live in the a2 buffer, which has no other use in shared-trunk mode
+    float *z3sh, *w3f;
+    const uint8_t *last_pos;
     signed char *ulist;
     float *slab;               // split-M partial sums
     size_t slab_floats;
@@ -148,6 +152,9 @@ static void refresh_transposes(grl_net *net) {
     for (const auto &l : L)
         hipLaunchKernelGGL(transpose_kernel, dim3((l.N + 31) / 32, (l.K + 31) / 32), dim3(32, 8), 0, net->h->stream, net->params + l.off,
                            l.K, l.N, net->paramsT + l.off);
+    for (int tap = 0; tap < 9; ++tap)     // w3f[(tap, co)][ci]: each tap's 64x64 block transposed
+        hipLaunchKernelGGL(transpose_kernel, dim3(2, 2), dim3(32, 8), 0, net->h->stream, net->params + ConvOffsets::c3w + tap * 4096, 64, 64,
+                           net->w3f + tap * 4096);
 }
 
 // ------------------------------------------------------------------------------------------ conv1 (sparse)
@@ -306,7 +313,7 @@ static int forward_chunk(grl_net *net, const uint8_t *lb, const uint8_t *ab, con
     const int n = nenv * 10;
     net->last_n = n;
     if (net->shared_trunk) {
-        int rc = forward_conv12_shared(net, lb, ab, pos, nenv, !reuse_tail);
+        int rc = forward_conv12_shared(net, lb, ab, pos, nenv, false);
         if (rc) return rc;
     } else {
     hipLaunchKernelGGL(conv1_sparse_kernel, dim3(nenv), dim3(256), 0, st, lb, ab, pos, P + ConvOffsets::c1w, P + ConvOffsets::c1b,
@@ -319,8 +326,11 @@ static int forward_chunk(grl_net *net, const uint8_t *lb, const uint8_t *ab, con
                            g, PT + ConvOffsets::c2w, 512, 64, e);
     }
     }
+    net->last_pos = pos;
     if (!reuse_tail) {
-    {
+    if (net->shared_trunk) {
+        if (int rc = forward_conv3_shared(net, nenv)) return rc;
+    } else {
         GatherConv3 g{net->a2, n * 49};
         EpiBiasAct e{net->a3, 64, P + ConvOffsets::c3b, ACT_RELU};
         GemmTimer t(net, 2.0 * n * 49 * 576 * 64);
@@ -408,6 +418,7 @@ int grl_net_create(grl_handle *h, const grl_net_config *cfg, grl_net **out) {
     n->T = 0; n->B = 0; n->tmp_envs = 0; n->act_counter = 0; n->prof_on = false; n->prof_used = 0; n->prof_flops = 0; n->last_n = 0;
     n->ro_lb = nullptr; n->slab = nullptr; n->slab_floats = 0; n->slab64 = nullptr; n->w3t = n->w2t = nullptr;
     n->ga1 = nullptr; n->mu = n->sigma = n->vs = nullptr;
+    n->last_pos = nullptr;
     n->keep = nullptr; n->keep_slots = 0; n->param_version = 0; n->keep_version = -1;
     size_t c = n->chunk;
     int rc = GRL_OK;
@@ -418,7 +429,7 @@ int grl_net_create(grl_handle *h, const grl_net_config *cfg, grl_net **out) {
     n->ws_a3 = n->a3; n->ws_d1 = n->d1; n->ws_d2 = n->d2; n->ws_p1 = n->p1; n->ws_v1 = n->v1; n->ws_v2 = n->v2;
     n->shared_trunk = (cfg->reserved & 1) ? 0 : 1;     // GRL_NET_F_PER_AGENT_TRUNK: the plain per-agent evaluation (A/B reference)
     A(&n->sraw, (c / 10) * 12800); A(&n->a1sh, (c / 10) * 12800); A(&n->z2sh, (c / 10) * 5184);
-    A(&n->a2sh, (c / 10) * 5184); A(&n->d2s, c * 9 * 64); A(&n->v2s, c * 9 * 64);
+    A(&n->a2sh, (c / 10) * 5184); A(&n->d2s, c * 9 * 64); A(&n->v2s, c * 9 * 64); A(&n->z3sh, (c / 10) * 3136); A(&n->w3f, 576 * 64);
     if (rc == GRL_OK) rc = nalloc(n, &n->ulist, c * 9);
     if (rc == GRL_OK) rc = ensure_tmp_obs(n, h->E);
     if (rc != GRL_OK) {
@@ -518,6 +529,19 @@ int grl_net_read_activation(grl_net *n, const char *which, float *host, size_t b
         if (bytes != need_e) return nfail(n, GRL_E_SIZE, "grl_net_read_activation: need " + std::to_string(need_e) + " bytes");
         NET_HIP(n, hipStreamSynchronize(n->h->stream));
         NET_HIP(n, hipMemcpy(host, w == "a1sh" ? n->a1sh : n->sraw, bytes, hipMemcpyDeviceToHost));
+        return GRL_OK;
+    }
+    else if (w == "a2" && n->shared_trunk) {     // not materialised in shared-trunk mode: expand it on demand (debug/test access)
+        size_t need_a = (size_t)n->last_n * 5184 * 4;
+        if (bytes != need_a) return nfail(n, GRL_E_SIZE, "grl_net_read_activation: need " + std::to_string(need_a) + " bytes");
+        if (!n->last_pos) return nfail(n, GRL_E_STATE, "grl_net_read_activation: no forward pass yet");
+        float *tmp = nullptr;
+        NET_HIP(n, hipMalloc((void **)&tmp, need_a));
+        hipLaunchKernelGGL(expand_conv2_kernel, dim3(n->last_n / 10), dim3(256), 0, n->h->stream, n->sraw, n->z2sh, n->last_pos,
+                           n->params + ConvOffsets::c1w, n->params + ConvOffsets::c2w, tmp, n->a2sh, n->d2s, n->v2s, n->ulist);
+        hipError_t e1 = hipStreamSynchronize(n->h->stream), e2 = hipMemcpy(host, tmp, bytes, hipMemcpyDeviceToHost);
+        (void)hipFree(tmp);
+        if (e1 != hipSuccess || e2 != hipSuccess) return nfail(n, GRL_E_HIP, "grl_net_read_activation: expanding a2 failed");
         return GRL_OK;
     }
     else if (w == "a2") { src = n->a2; per = 5184; }
