@@ -64,7 +64,6 @@ struct grl_net {
     // shared conv3 forward: z3sh = conv3(a2sh) + b3 per env, w3f[(tap,co)][ci] = W3[tap][ci][co]; the per-slot products
     // (a2_a - a2sh)[u] . W3[tap] (n*9 x 576) live in the a2 buffer, which has no other use in shared-trunk mode
     float *z3sh, *w3f;
-    const uint8_t *last_pos;
     signed char *ulist;
     float *slab;               // split-M partial sums
     size_t slab_floats;
@@ -313,7 +312,7 @@ static int forward_chunk(grl_net *net, const uint8_t *lb, const uint8_t *ab, con
     const int n = nenv * 10;
     net->last_n = n;
     if (net->shared_trunk) {
-        int rc = forward_conv12_shared(net, lb, ab, pos, nenv, false);
+        int rc = forward_conv12_shared(net, lb, ab, pos, nenv);
         if (rc) return rc;
     } else {
     hipLaunchKernelGGL(conv1_sparse_kernel, dim3(nenv), dim3(256), 0, st, lb, ab, pos, P + ConvOffsets::c1w, P + ConvOffsets::c1b,
@@ -326,7 +325,6 @@ static int forward_chunk(grl_net *net, const uint8_t *lb, const uint8_t *ab, con
                            g, PT + ConvOffsets::c2w, 512, 64, e);
     }
     }
-    net->last_pos = pos;
     if (!reuse_tail) {
     if (net->shared_trunk) {
         if (int rc = forward_conv3_shared(net, nenv)) return rc;
@@ -418,7 +416,6 @@ int grl_net_create(grl_handle *h, const grl_net_config *cfg, grl_net **out) {
     n->T = 0; n->B = 0; n->tmp_envs = 0; n->act_counter = 0; n->prof_on = false; n->prof_used = 0; n->prof_flops = 0; n->last_n = 0;
     n->ro_lb = nullptr; n->slab = nullptr; n->slab_floats = 0; n->slab64 = nullptr; n->w3t = n->w2t = nullptr;
     n->ga1 = nullptr; n->mu = n->sigma = n->vs = nullptr;
-    n->last_pos = nullptr;
     n->keep = nullptr; n->keep_slots = 0; n->param_version = 0; n->keep_version = -1;
     size_t c = n->chunk;
     int rc = GRL_OK;
@@ -431,6 +428,9 @@ int grl_net_create(grl_handle *h, const grl_net_config *cfg, grl_net **out) {
     A(&n->sraw, (c / 10) * 12800); A(&n->a1sh, (c / 10) * 12800); A(&n->z2sh, (c / 10) * 5184);
     A(&n->a2sh, (c / 10) * 5184); A(&n->d2s, c * 9 * 64); A(&n->v2s, c * 9 * 64); A(&n->z3sh, (c / 10) * 3136); A(&n->w3f, 576 * 64);
     if (rc == GRL_OK) rc = nalloc(n, &n->ulist, c * 9);
+    if (rc == GRL_OK && hipFuncSetAttribute((const void *)expand_conv2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)EXP2_LDS_BYTES) != hipSuccess)
+        rc = nfail(n, GRL_E_HIP, "hipFuncSetAttribute(expand_conv2_kernel)");
     if (rc == GRL_OK) rc = ensure_tmp_obs(n, h->E);
     if (rc != GRL_OK) {
         fail(h, rc, "grl_net_create: " + n->err);
@@ -534,11 +534,10 @@ int grl_net_read_activation(grl_net *n, const char *which, float *host, size_t b
     else if (w == "a2" && n->shared_trunk) {     // not materialised in shared-trunk mode: expand it on demand (debug/test access)
         size_t need_a = (size_t)n->last_n * 5184 * 4;
         if (bytes != need_a) return nfail(n, GRL_E_SIZE, "grl_net_read_activation: need " + std::to_string(need_a) + " bytes");
-        if (!n->last_pos) return nfail(n, GRL_E_STATE, "grl_net_read_activation: no forward pass yet");
+        if (n->last_n <= 0) return nfail(n, GRL_E_STATE, "grl_net_read_activation: no forward pass yet");
         float *tmp = nullptr;
         NET_HIP(n, hipMalloc((void **)&tmp, need_a));
-        hipLaunchKernelGGL(expand_conv2_kernel, dim3(n->last_n / 10), dim3(256), 0, n->h->stream, n->sraw, n->z2sh, n->last_pos,
-                           n->params + ConvOffsets::c1w, n->params + ConvOffsets::c2w, tmp, n->a2sh, n->d2s, n->v2s, n->ulist);
+        hipLaunchKernelGGL(materialize_a2_kernel, dim3(n->last_n), dim3(256), 0, n->h->stream, n->a2sh, n->v2s, n->ulist, tmp);
         hipError_t e1 = hipStreamSynchronize(n->h->stream), e2 = hipMemcpy(host, tmp, bytes, hipMemcpyDeviceToHost);
         (void)hipFree(tmp);
         if (e1 != hipSuccess || e2 != hipSuccess) return nfail(n, GRL_E_HIP, "grl_net_read_activation: expanding a2 failed");
