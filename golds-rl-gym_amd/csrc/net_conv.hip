@@ -61,6 +61,8 @@ struct grl_net {
     // shared conv3 gradients: per-env a2sh = relu(z2sh), DZ3; per (agent, slot <= 9 touched conv2 pixels): pixel id,
     // a2_a[u], a2_a[u] - a2sh[u], T3(dz3_a)[u], masked dz2_a[u]; tmpw3: correction GEMM output before the tap flip
     float *a2sh, *d2s, *v2s, *gsl, *dza, *dz3sh, *tmpw3;
+    float *at2, *dl2, *tt2, *tmpw2;   // conv2-level corrections as class-major GEMM operands (net_shared.inc)
+    int npad;
     // shared conv3 forward: z3sh = conv3(a2sh) + b3 per env, w3f[(tap,co)][ci] = W3[tap][ci][co]; the per-slot products
     // (a2_a - a2sh)[u] . W3[tap] (n*9 x 576) live in the a2 buffer, which has no other use in shared-trunk mode
     float *z3sh, *w3f;
