@@ -95,7 +95,7 @@ def _cpu_cores():
     return min(ncores, 32)
 
 
-def cpu_baseline(sample_envs, T, full_update_envs=16):
+def cpu_baseline(sample_envs, T, full_update_envs=48):
     """CPU baseline from the oracle ("port"), bounded sample of the SAME workload: a full PAAC update
     (dense 84x84x3 images as the reference builds them, conv policy forward per step, C env step + observation,
     n-step returns, loss + backward over the T*E*10 samples) on `full_update_envs` envs; numpy/BLAS threads +
@@ -274,9 +274,14 @@ def main():
         if gemm is not None:
             launches, ms, flops = gemm
             ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            gtraffic = None      # HBM bytes per GEMM launch from the committed PMC passes (same 40 960-sample chunks)
+            gpath = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")
+            if os.path.exists(gpath):
+                with open(gpath) as f:
+                    gtraffic = json.load(f).get("hbm_bytes_per_launch")
             out["roofline"] = {"bound": "mfma", "kernel": "gemm_rowk / gemm_tn (fp32 v_mfma_f32_32x32x2_f32 implicit GEMMs)",
                                "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TFLOPS,
-                               "traffic": None, "launches": launches, "gemm_ms_total": ms,
+                               "traffic": gtraffic, "launches": launches, "gemm_ms_total": ms,
                                "gemm_share_of_step": (ms * 1e-3) / elapsed if world == 1 else None,
                                "flops_per_launch_avg": flops / max(launches, 1)}
             out["roofline_env_step"] = env_roof

@@ -23,3 +23,23 @@ with open("gpurun_out/%s_summary.csv" % tag, "w") as f:
                                                      r["Percentage"], pmc.get(k, {}).get("fetch", float("nan")),
                                                      pmc.get(k, {}).get("write", float("nan"))))
 print(open("gpurun_out/%s_summary.csv" % tag).read()[:6000])
+
+# aggregate HBM-side traffic of the MFMA GEMM kernels (bench.py's roofline.traffic): FETCH_SIZE x2 (gfx950 wide
+# coalesced reads count half, MI355X_MICROARCH.md HBM/rocprofv3 section), WRITE_SIZE as is, unit KB
+import json
+g_calls = 0
+g_bytes = 0.0
+g_ns = 0.0
+for r in rows:
+    k = r["Name"]
+    if k.startswith("void grl::gemm_rowk") or k.startswith("void grl::gemm_tn"):
+        c = int(r["Calls"])
+        g_calls += c
+        g_ns += float(r["TotalDurationNs"])
+        g_bytes += c * 1024.0 * (2.0 * pmc.get(k, {}).get("fetch", 0.0) + pmc.get(k, {}).get("write", 0.0))
+json.dump({"kernels": "gemm_rowk / gemm_tn (all instantiations)", "launches": g_calls, "avg_launch_us": g_ns / 1e3 / max(g_calls, 1),
+           "hbm_bytes_per_launch": g_bytes / max(g_calls, 1), "hbm_bytes_total": g_bytes,
+           "correction": "FETCH_SIZE x2 (gfx950), WRITE_SIZE as is, unit KB; per-kernel averages weighted by calls",
+           "source": "tools/run_prof.sh %s (rocprofv3 --kernel-trace --stats / --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes)" % tag},
+          open("gpurun_out/%s_gemm_traffic.json" % tag, "w"), indent=1)
+print(open("gpurun_out/%s_gemm_traffic.json" % tag).read())
