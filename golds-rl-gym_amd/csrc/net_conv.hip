@@ -66,6 +66,12 @@ struct grl_net {
     // shared conv3 forward: z3sh = conv3(a2sh) + b3 per env, w3f[(tap,co)][ci] = W3[tap][ci][co]; the per-slot products
     // (a2_a - a2sh)[u] . W3[tap] (n*9 x 576) live in the a2 buffer, which has no other use in shared-trunk mode
     float *z3sh, *w3f;
+    // dense1 on the shared a3 (net_patch.inc): per-env a3sh and ysh = W^T a3sh + b; per agent the 5x5 patch values v3 and
+    // differences d3 (1600 floats); group-sorted sample order for the patch GEMMs
+    float *a3sh, *d3, *v3, *ysh;
+    float *gd1sh, *gsh3, *g3p, *dz3p;     // gradient side: per-env sum of gd1, its dense1 data gradient, per-agent patch gradients
+    int *perm, *goffp, *blkcnt, *blkoff, *sbeg, *send, *sgrp, ptiles, pslices;
+    signed char *tilegroup, *org;
     signed char *ulist;
     float *slab;               // split-M partial sums
     size_t slab_floats;
@@ -92,7 +98,7 @@ struct grl_net {
     // the gradient step reads them back instead of recomputing conv3 and the dense stack.  Exact: parameters do
     // not change between the two (paac.py:302-387).  keep_version tracks that; GRL_NET_F_RECOMPUTE_FORWARD or too
     // little free memory selects recomputation.
-    float *ws_a3, *ws_d1, *ws_d2, *ws_p1, *ws_v1, *ws_v2;   // chunk workspace (the default binding of a3..v2)
+    float *ws_a3, *ws_d1, *ws_d2, *ws_p1, *ws_v1, *ws_v2, *ws_a3sh, *ws_d3, *ws_v3;   // chunk workspace (the default binding)
     float *keep;
     size_t keep_slots;
     long param_version, keep_version;
@@ -285,19 +291,32 @@ __global__ void sample_actions_kernel(const float *__restrict__ mu, const float 
 }
 
 #include "net_shared.inc"
+#include "net_patch.inc"
 
 // ------------------------------------------------------------------------------------------ forward pass of one chunk
-static constexpr size_t KEEP_FLOATS_PER_SAMPLE = 3136 + 512 + 256 + 512 + 512 + 256;
+// floats kept per chunk slot: per-agent-trunk mode a3 + dense stack; shared mode a3sh (per env) + d3 + v3 + dense stack
+static size_t keep_floats_per_slot(const grl_net *net) {
+    const size_t c = net->chunk, dense = 512 + 256 + 512 + 512 + 256;
+    return net->shared_trunk ? (c / 10) * 3136 + c * (1600 + 1600 + dense) : c * (3136 + dense);
+}
 
-// a3..v2 point into slot `slot` of the rollout-resident buffer, or at the chunk workspace for slot < 0
+// the activations the gradient step reads point into slot `slot` of the rollout-resident buffer, or at the chunk
+// workspace for slot < 0
 static void bind_activations(grl_net *net, long slot) {
     if (slot < 0 || !net->keep) {
         net->a3 = net->ws_a3; net->d1 = net->ws_d1; net->d2 = net->ws_d2; net->p1 = net->ws_p1; net->v1 = net->ws_v1; net->v2 = net->ws_v2;
+        net->a3sh = net->ws_a3sh; net->d3 = net->ws_d3; net->v3 = net->ws_v3;
         return;
     }
     const size_t c = net->chunk;
-    float *b = net->keep + (size_t)slot * c * KEEP_FLOATS_PER_SAMPLE;
-    net->a3 = b; b += c * 3136;
+    float *b = net->keep + (size_t)slot * keep_floats_per_slot(net);
+    if (net->shared_trunk) {
+        net->a3sh = b; b += (c / 10) * 3136;
+        net->d3 = b; b += c * 1600;
+        net->v3 = b; b += c * 1600;
+    } else {
+        net->a3 = b; b += c * 3136;
+    }
     net->d1 = b; b += c * 512;
     net->d2 = b; b += c * 256;
     net->p1 = b; b += c * 512;
@@ -329,7 +348,7 @@ static int forward_chunk(grl_net *net, const uint8_t *lb, const uint8_t *ab, con
     }
     if (!reuse_tail) {
     if (net->shared_trunk) {
-        if (int rc = forward_conv3_shared(net, nenv)) return rc;
+        if (int rc = forward_conv3_dense1_shared(net, nenv)) return rc;
     } else {
         GatherConv3 g{net->a2, n * 49};
         EpiBiasAct e{net->a3, 64, P + ConvOffsets::c3b, ACT_RELU};
@@ -344,7 +363,7 @@ static int forward_chunk(grl_net *net, const uint8_t *lb, const uint8_t *ab, con
         hipLaunchKernelGGL((gemm_rowk<128, 128, 2, 2, DenseRows, EpiBiasAct>), dim3(N / 128, (n + 127) / 128), dim3(256), 0, st, g,
                            w, K, N, e);
     };
-    dense(net->a3, 3136, PT + ConvOffsets::d1w, P + ConvOffsets::d1b, 512, net->d1);
+    if (!net->shared_trunk) dense(net->a3, 3136, PT + ConvOffsets::d1w, P + ConvOffsets::d1b, 512, net->d1);
     dense(net->d1, 512, PT + ConvOffsets::d2w, P + ConvOffsets::d2b, 256, net->d2);
     dense(net->d2, 256, PT + ConvOffsets::p1w, P + ConvOffsets::p1b, 512, net->p1);
     dense(net->d2, 256, PT + ConvOffsets::v1w, P + ConvOffsets::v1b, 512, net->v1);
@@ -430,6 +449,19 @@ int grl_net_create(grl_handle *h, const grl_net_config *cfg, grl_net **out) {
     A(&n->sraw, (c / 10) * 12800); A(&n->a1sh, (c / 10) * 12800); A(&n->z2sh, (c / 10) * 5184);
     A(&n->a2sh, (c / 10) * 5184); A(&n->d2s, c * 9 * 64); A(&n->v2s, c * 9 * 64); A(&n->z3sh, (c / 10) * 3136); A(&n->w3f, 576 * 64);
     if (rc == GRL_OK) rc = nalloc(n, &n->ulist, c * 9);
+    n->ptiles = (int)((c + 255) / 256) + 9;
+    A(&n->a3sh, (c / 10) * 3136); A(&n->d3, c * 1600); A(&n->v3, c * 1600); A(&n->ysh, (c / 10) * 512);
+    n->ws_a3sh = n->a3sh; n->ws_d3 = n->d3; n->ws_v3 = n->v3;
+    if (rc == GRL_OK) rc = nalloc(n, &n->perm, (size_t)n->ptiles * 256);
+    if (rc == GRL_OK) rc = nalloc(n, &n->goffp, 16);
+    n->pslices = (int)((c + 1023) / 1024) + 9;
+    if (rc == GRL_OK) rc = nalloc(n, &n->sbeg, n->pslices);
+    if (rc == GRL_OK) rc = nalloc(n, &n->send, n->pslices);
+    if (rc == GRL_OK) rc = nalloc(n, &n->sgrp, n->pslices);
+    if (rc == GRL_OK) rc = nalloc(n, &n->blkcnt, ((c + 255) / 256) * 9);
+    if (rc == GRL_OK) rc = nalloc(n, &n->blkoff, ((c + 255) / 256) * 9);
+    if (rc == GRL_OK) rc = nalloc(n, &n->tilegroup, (size_t)n->ptiles);
+    if (rc == GRL_OK) rc = nalloc(n, &n->org, c);
     if (rc == GRL_OK && hipFuncSetAttribute((const void *)expand_conv2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int)EXP2_LDS_BYTES) != hipSuccess)
         rc = nfail(n, GRL_E_HIP, "hipFuncSetAttribute(expand_conv2_kernel)");
@@ -546,6 +578,18 @@ int grl_net_read_activation(grl_net *n, const char *which, float *host, size_t b
         return GRL_OK;
     }
     else if (w == "a2") { src = n->a2; per = 5184; }
+    else if (w == "a3" && n->shared_trunk) {     // likewise: a3sh with the agent's 5x5 patch replaced by v3
+        size_t need_a = (size_t)n->last_n * 3136 * 4;
+        if (bytes != need_a) return nfail(n, GRL_E_SIZE, "grl_net_read_activation: need " + std::to_string(need_a) + " bytes");
+        if (n->last_n <= 0) return nfail(n, GRL_E_STATE, "grl_net_read_activation: no forward pass yet");
+        float *tmp = nullptr;
+        NET_HIP(n, hipMalloc((void **)&tmp, need_a));
+        hipLaunchKernelGGL(materialize_a3_kernel, dim3(n->last_n), dim3(256), 0, n->h->stream, n->a3sh, n->v3, n->org, tmp);
+        hipError_t e1 = hipStreamSynchronize(n->h->stream), e2 = hipMemcpy(host, tmp, bytes, hipMemcpyDeviceToHost);
+        (void)hipFree(tmp);
+        if (e1 != hipSuccess || e2 != hipSuccess) return nfail(n, GRL_E_HIP, "grl_net_read_activation: expanding a3 failed");
+        return GRL_OK;
+    }
     else if (w == "a3") { src = n->a3; per = 3136; }
     else if (w == "d1") { src = n->d1; per = 512; }
     else if (w == "d2") { src = n->d2; per = 256; }

@@ -58,6 +58,12 @@ struct ConvGather {
         return !CHECK || ((unsigned)(iy0 + ty) < (unsigned)H && (unsigned)(ix0 + tx) < (unsigned)W);
     }
     __device__ __forceinline__ bool tile_ok(int, int) const { return true; }
+    __device__ __forceinline__ bool tile_active(int) const { return true; }
+    __device__ __forceinline__ int bk(int k0, int) const { return k0; }
+    __device__ __forceinline__ int bn(int n0, int) const { return n0; }
+    __device__ __forceinline__ int rowidx(int m) const { return m; }
+    __device__ __forceinline__ void rowp(int p, long &off, int &iy0, int &ix0) const { row(p, off, iy0, ix0); }
+    __device__ __forceinline__ void mrange(int z, int mc, int &mbeg, int &mend) const { mbeg = z * mc; mend = min(rows, mbeg + mc); }
 };
 
 // Pixel-major variant for stride-1 transposed convolutions: row r = q*nsamp + n (pixel q of sample n), so when
@@ -91,6 +97,12 @@ struct ConvGatherPM {
         int t = k0 / C, ty = t / P, tx = t - ty * P;
         return ok(qy + OY0, qx + OX0, ty, tx);
     }
+    __device__ __forceinline__ bool tile_active(int) const { return true; }
+    __device__ __forceinline__ int bk(int k0, int) const { return k0; }
+    __device__ __forceinline__ int bn(int n0, int) const { return n0; }
+    __device__ __forceinline__ int rowidx(int m) const { return m; }
+    __device__ __forceinline__ void rowp(int p, long &off, int &iy0, int &ix0) const { row(p, off, iy0, ix0); }
+    __device__ __forceinline__ void mrange(int z, int mc, int &mbeg, int &mend) const { mbeg = z * mc; mend = min(rows, mbeg + mc); }
 };
 
 // conv3's transposed convolution evaluated only at the <= 9 conv2 pixels an agent's one-hot can reach:
@@ -119,6 +131,12 @@ struct SlotGatherT3 {
         return (unsigned)(iy0 + ty) < 7u && (unsigned)(ix0 + tx) < 7u;
     }
     __device__ __forceinline__ bool tile_ok(int, int) const { return true; }
+    __device__ __forceinline__ bool tile_active(int) const { return true; }
+    __device__ __forceinline__ int bk(int k0, int) const { return k0; }
+    __device__ __forceinline__ int bn(int n0, int) const { return n0; }
+    __device__ __forceinline__ int rowidx(int m) const { return m; }
+    __device__ __forceinline__ void rowp(int p, long &off, int &iy0, int &ix0) const { row(p, off, iy0, ix0); }
+    __device__ __forceinline__ void mrange(int z, int mc, int &mbeg, int &mend) const { mbeg = z * mc; mend = min(rows, mbeg + mc); }
 };
 
 struct DenseRows {   // plain row-major [rows][ld], reduction length k
@@ -135,6 +153,95 @@ struct DenseRows {   // plain row-major [rows][ld], reduction length k
     }
     __device__ __forceinline__ bool ok(int, int, int, int) const { return true; }
     __device__ __forceinline__ bool tile_ok(int, int) const { return true; }
+    __device__ __forceinline__ bool tile_active(int) const { return true; }
+    __device__ __forceinline__ int bk(int k0, int) const { return k0; }
+    __device__ __forceinline__ int bn(int n0, int) const { return n0; }
+    __device__ __forceinline__ int rowidx(int m) const { return m; }
+    __device__ __forceinline__ void rowp(int p, long &off, int &iy0, int &ix0) const { row(p, off, iy0, ix0); }
+    __device__ __forceinline__ void mrange(int z, int mc, int &mbeg, int &mend) const { mbeg = z * mc; mend = min(rows, mbeg + mc); }
+};
+
+// Same on the patch-compact per-agent dz3 (net_patch.inc): base[n][py][px][co] (5x5 window with origin org[n] = oy*3+ox);
+// every pixel u - 2 + t inside the 7x7 map lies inside the agent's window by construction.
+struct SlotGatherT3P {
+    const float *base;
+    const signed char *ulist, *org;
+    int rows;
+    __device__ __forceinline__ int K() const { return 576; }
+    __device__ __forceinline__ void row(int r, long &off, int &iy0, int &ix0) const {
+        const int n = r / 9, u = ulist[r], g = org[n];
+        const int qy = u / 9, qx = u - qy * 9, oy = g / 3, ox = g - oy * 3;
+        iy0 = u < 0 ? -16 : qy - 2;
+        ix0 = u < 0 ? -16 : qx - 2;
+        off = (long)n * 1600 + ((long)(iy0 - oy) * 5 + (ix0 - ox)) * 64;
+    }
+    __device__ __forceinline__ void tap(int k0, int &toff, int &ty, int &tx) const {
+        int t = k0 >> 6;
+        int c0 = k0 & 63;
+        ty = t / 3;
+        tx = t - ty * 3;
+        toff = (ty * 5 + tx) * 64 + c0;
+    }
+    __device__ __forceinline__ bool ok(int iy0, int ix0, int ty, int tx) const {
+        return (unsigned)(iy0 + ty) < 7u && (unsigned)(ix0 + tx) < 7u;
+    }
+    __device__ __forceinline__ bool tile_ok(int, int) const { return true; }
+    __device__ __forceinline__ bool tile_active(int) const { return true; }
+    __device__ __forceinline__ int bk(int k0, int) const { return k0; }
+    __device__ __forceinline__ int bn(int n0, int) const { return n0; }
+    __device__ __forceinline__ int rowidx(int m) const { return m; }
+    __device__ __forceinline__ void rowp(int p, long &off, int &iy0, int &ix0) const { row(p, off, iy0, ix0); }
+    __device__ __forceinline__ void mrange(int z, int mc, int &mbeg, int &mend) const { mbeg = z * mc; mend = min(rows, mbeg + mc); }
+};
+
+// dense1 on the shared a3 (net_patch.inc): an agent's a3 differs from its env's a3sh only inside a 5x5 window ("patch",
+// origin (oy, ox) in {0,1,2}^2 = group g) of the 7x7 map.  Samples are sorted by group into 256-row tiles (perm[slot] =
+// sample or -1 for padding, tilegroup[slot >> 8] = g or -1), so that one workgroup multiplies against ONE group's 1600
+// rows of the dense1 kernel: patch element (py, px, c) <-> dense1 input ((oy+py)*7 + ox+px)*64 + c.
+//   mode 0: the reduction runs over the patch (forward, weight gradient): B's k offset is remapped per 320-float strip
+//   mode 1: the output columns are the patch (data gradient): B's row base is remapped per 64-column tile (one pixel)
+struct PatchRows {
+    const float *base;
+    const int *perm;
+    const signed char *tilegroup;
+    int rows, ld, k, mode;
+    const int *sbeg, *send;      // gemm_tn only: grid z = slice of <= 1024 sorted rows inside one group (empty: sbeg == send)
+    __device__ __forceinline__ int rowidx(int m) const { return perm[m]; }      // gemm_tn: fetched one tile ahead
+    __device__ __forceinline__ void rowp(int p, long &off, int &iy0, int &ix0) const {
+        iy0 = 0;
+        ix0 = 0;
+        off = (long)p * ld;
+    }
+    __device__ __forceinline__ void mrange(int z, int, int &mbeg, int &mend) const {
+        mbeg = sbeg[z];
+        mend = send[z];
+    }
+    __device__ __forceinline__ int K() const { return k; }
+    __device__ __forceinline__ void row(int r, long &off, int &iy0, int &ix0) const {
+        const int m = perm[r];
+        iy0 = m < 0 ? -1 : 0;
+        ix0 = 0;
+        off = (long)(m < 0 ? 0 : m) * ld;
+    }
+    __device__ __forceinline__ void tap(int k0, int &toff, int &ty, int &tx) const {
+        toff = k0;
+        ty = tx = 0;
+    }
+    __device__ __forceinline__ bool ok(int iy0, int, int, int) const { return iy0 >= 0; }
+    __device__ __forceinline__ bool tile_ok(int, int) const { return true; }
+    __device__ __forceinline__ bool tile_active(int m0) const { return tilegroup[m0 >> 8] >= 0; }
+    __device__ __forceinline__ int bk(int k0, int m0) const {
+        if (mode != 0) return k0;
+        const int g = tilegroup[m0 >> 8], oy = g / 3, ox = g - oy * 3;
+        const int py = k0 / 320, rest = k0 - py * 320;
+        return ((oy + py) * 7 + ox) * 64 + rest;
+    }
+    __device__ __forceinline__ int bn(int n0, int m0) const {
+        if (mode != 1) return n0;
+        const int g = tilegroup[m0 >> 8], oy = g / 3, ox = g - oy * 3;
+        const int j = n0 >> 6, py = j / 5, px = j - py * 5;
+        return ((oy + py) * 7 + ox + px) * 64 + (n0 & 63);
+    }
 };
 
 // ---------------------------------------------------------------------------- epilogues
@@ -149,6 +256,27 @@ struct EpiBiasAct {   // C[r][c] = act(v + bias[c])
         v += bias[c];
         if (act == ACT_RELU) v = fmaxf(v, 0.f);
         C[(long)r * ldc + c] = v;
+    }
+};
+
+struct EpiPatchFwd {   // sorted row -> sample m: out[m][c] = relu(v + ysh[env(m)][c]) (ysh = per-env part incl. bias)
+    float *out;
+    const float *ysh;
+    const int *perm;
+    int ld;
+    __device__ __forceinline__ void operator()(int r, int c, float v) const {
+        const int m = perm[r];
+        if (m >= 0) out[(long)m * ld + c] = fmaxf(v + ysh[(long)(m / 10) * ld + c], 0.f);
+    }
+};
+
+struct EpiPermStore {   // sorted row -> sample m: out[m][c] = v
+    float *out;
+    const int *perm;
+    int ld;
+    __device__ __forceinline__ void operator()(int r, int c, float v) const {
+        const int m = perm[r];
+        if (m >= 0) out[(long)m * ld + c] = v;
     }
 };
 
@@ -207,6 +335,7 @@ __global__ __launch_bounds__(256, 2) void gemm_rowk(AG ag, const float *__restri
     // N tiles vary fastest in launch order: the workgroups that share one A tile run together, so it is
     // fetched from HBM once and served to the others by L2 (the B operand is small and always cached)
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    if (!ag.tile_active(m0)) return;     // block-uniform (padding tiles of the group-sorted layouts)
     const int M = ag.rows, K = ag.K();
     const int trow = tid >> 3, tk4 = (tid & 7) * 4;
 
@@ -223,7 +352,7 @@ __global__ __launch_bounds__(256, 2) void gemm_rowk(AG ag, const float *__restri
         ayx[i] = (iy0 << 16) | (ix0 & 0xFFFF);
     }
     static_assert(NB == 1 || NB == 2 || NB == 4, "B tile of 32, 64 or 128 rows");
-    const float *brow0 = Bt + (long)(n0 + trow) * ldb + tk4;
+    const float *brow0 = Bt + (long)(ag.bn(n0, m0) + trow) * ldb + tk4;
 
     float4 ra[NA];
     float4 rb0 = make_float4(0.f, 0.f, 0.f, 0.f), rb1 = rb0, rb2 = rb0, rb3 = rb0;
@@ -241,10 +370,11 @@ __global__ __launch_bounds__(256, 2) void gemm_rowk(AG ag, const float *__restri
             vmask = v ? (vmask | (1u << i)) : (vmask & ~(1u << i));   /* the zero-fill select happens at store time */ \
         }                                                                                                  \
         /* named scalars, not an array: an array here is "promoted" to LDS by the compiler */             \
-        rb0 = *reinterpret_cast<const float4 *>(brow0 + (kt_) * BK);                                       \
-        if (NB > 1) rb1 = *reinterpret_cast<const float4 *>(brow0 + (long)32 * ldb + (kt_) * BK);          \
-        if (NB > 2) rb2 = *reinterpret_cast<const float4 *>(brow0 + (long)64 * ldb + (kt_) * BK);          \
-        if (NB > 2) rb3 = *reinterpret_cast<const float4 *>(brow0 + (long)96 * ldb + (kt_) * BK);          \
+        const int bko = ag.bk((kt_) * BK, m0);                                                             \
+        rb0 = *reinterpret_cast<const float4 *>(brow0 + bko);                                              \
+        if (NB > 1) rb1 = *reinterpret_cast<const float4 *>(brow0 + (long)32 * ldb + bko);                 \
+        if (NB > 2) rb2 = *reinterpret_cast<const float4 *>(brow0 + (long)64 * ldb + bko);                 \
+        if (NB > 2) rb3 = *reinterpret_cast<const float4 *>(brow0 + (long)96 * ldb + bko);                 \
     }
 #define GRL_STORE_TILE()                                                                                   \
     {                                                                                                      \
@@ -340,34 +470,44 @@ __global__ __launch_bounds__(256) void gemm_tn(AG ag, const float *__restrict__ 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave - wm * WGN;
     const int i0 = blockIdx.x * BM, j0 = blockIdx.y * BN;
-    const int M = ag.rows, I = ag.K();
-    const int mbeg = blockIdx.z * mc;
-    const int mend = min(M, mbeg + mc);
+    const int I = ag.K();
+    int mbeg, mend;
+    ag.mrange(blockIdx.z, mc, mbeg, mend);
 
     int toff, ty, tx;
     ag.tap(i0, toff, ty, tx);   // the BM-wide column run lies inside one tap row (checked on the host)
 
     float4 ra[NA], rb[NB];
     unsigned vma = 0, vmb = 0;
-#define GRL_LOAD_TILE(mt_)                                                                                         \
+    // physical rows of the tile about to be loaded (-1: past the range / padding).  They are fetched one tile ahead of
+    // the data so that an indirection (PatchRows' sorted order) does not put two dependent global loads in one stage.
+    int ia[NA], ib[NB];
+#define GRL_LOAD_IDX(mt_)                                                                                          \
     {                                                                                                              \
         _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                           \
-            int idx = tid + 256 * i;                                                                               \
-            int kk = idx / A4, c4 = idx - kk * A4;                                                                 \
-            int m = (mt_) + kk;                                                                                    \
-            const bool inr = m < mend;                                                                             \
+            const int m = (mt_) + (tid + 256 * i) / A4;                                                            \
+            ia[i] = m < mend ? ag.rowidx(m) : -1;                                                                  \
+        }                                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                           \
+            const int m = (mt_) + (tid + 256 * i) / B4;                                                            \
+            ib[i] = m < mend ? ag.rowidx(m) : -1;                                                                  \
+        }                                                                                                          \
+    }
+#define GRL_LOAD_TILE()                                                                                            \
+    {                                                                                                              \
+        _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                           \
+            const int c4 = (tid + 256 * i) % A4;                                                                   \
+            const bool inr = ia[i] >= 0;                                                                           \
             long off; int iy0, ix0;                                                                                \
-            ag.row(inr ? m : mbeg, off, iy0, ix0);                                                                 \
+            ag.rowp(inr ? ia[i] : 0, off, iy0, ix0);                                                               \
             const bool v = inr && ag.ok(iy0, ix0, ty, tx);                                                         \
             ra[i] = *reinterpret_cast<const float4 *>(ag.base + (v ? off + toff : 0L) + c4 * 4);                   \
             vma = v ? (vma | (1u << i)) : (vma & ~(1u << i));                                                      \
         }                                                                                                          \
         _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                           \
-            int idx = tid + 256 * i;                                                                               \
-            int kk = idx / B4, c4 = idx - kk * B4;                                                                 \
-            int m = (mt_) + kk;                                                                                    \
-            const bool v = m < mend;                                                                               \
-            rb[i] = *reinterpret_cast<const float4 *>(dY + (long)(v ? m : mbeg) * J + j0 + c4 * 4);                \
+            const int c4 = (tid + 256 * i) % B4;                                                                   \
+            const bool v = ib[i] >= 0;                                                                             \
+            rb[i] = *reinterpret_cast<const float4 *>(dY + (long)(v ? ib[i] : 0) * J + j0 + c4 * 4);               \
             vmb = v ? (vmb | (1u << i)) : (vmb & ~(1u << i));                                                      \
         }                                                                                                          \
     }
@@ -395,14 +535,14 @@ __global__ __launch_bounds__(256) void gemm_tn(AG ag, const float *__restrict__ 
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     const int lr = lane & 31, lk = lane >> 5;
     if (mbeg < mend) {
-        GRL_LOAD_TILE(mbeg)
+        GRL_LOAD_IDX(mbeg)
+        GRL_LOAD_TILE()
+        GRL_LOAD_IDX(mbeg + BK)
         for (int mt = mbeg; mt < mend; mt += BK) {
             GRL_STORE_TILE()
             __syncthreads();
-            {
-                const int mtn = mt + BK < mend ? mt + BK : mt;
-                GRL_LOAD_TILE(mtn)
-            }
+            GRL_LOAD_TILE()                  // rows mt + BK .. (row 0, masked, past the end of the range)
+            GRL_LOAD_IDX(mt + 2 * BK)
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int kk = 0; kk < BK; kk += 2) {
@@ -432,6 +572,7 @@ __global__ __launch_bounds__(256) void gemm_tn(AG ag, const float *__restrict__ 
                 if (row < I && col < J) out[(long)row * J + col] = acc[a][b][r];
             }
 #undef GRL_LOAD_TILE
+#undef GRL_LOAD_IDX
 #undef GRL_STORE_TILE
 }
 
