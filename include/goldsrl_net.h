@@ -21,11 +21,12 @@ extern "C" {
 #endif
 
 #define GRL_NET_CONV_SINGLE_AGENT 0 /* policy_v_network.py:5-66; Swarm handles only */
-/* Evaluate conv1/conv2 per agent image instead of once per env + exact per-agent corrections (the default,
- * csrc/net_shared.inc).  Same sums, different association; kept as the A/B reference of the optimisation. */
+/* Evaluate the whole net per agent image, as the reference does, instead of the default shared evaluation (conv1-conv3
+ * once per env + exact per-agent corrections, dense1 split into a per-env part and a 5x5 patch part: csrc/net_shared.inc,
+ * csrc/net_patch.inc).  Same sums, different association; kept as the A/B reference of the optimisation. */
 #define GRL_NET_F_PER_AGENT_TRUNK 0x1
 /* Recompute conv3 and the dense stack in the gradient step instead of keeping the rollout's activations resident
- * in HBM (20.7 KB per agent-sample and step; chosen automatically when that buffer does not fit).  Bit-identical. */
+ * in HBM (22 KB per agent-sample and step; chosen automatically when that buffer does not fit).  Bit-identical. */
 #define GRL_NET_F_RECOMPUTE_FORWARD 0x2
 
 typedef struct grl_net_config {
@@ -81,7 +82,8 @@ int grl_net_train_obs(grl_net *net, int32_t n_envs, const uint8_t *locust_bins, 
 int grl_net_read_rollout(grl_net *net, const char *which, void *host, size_t bytes);
 /* Debug/test access to a forward activation of the last chunk: "a1" (n,20,20,32) "a2" (n,9,9,64)
  * "a3" (n,7,7,64) "d1" (n,512) "d2" (n,256) "p1" (n,512) "v1" (n,512) "v2" (n,256); "a1" only with
- * GRL_NET_F_PER_AGENT_TRUNK, otherwise the per-env "a1sh"/"sraw" (n/10,20,20,32). */
+ * GRL_NET_F_PER_AGENT_TRUNK, otherwise the per-env "a1sh"/"sraw" (n/10,20,20,32).  In the default shared evaluation the
+ * per-agent "a2"/"a3" are not materialised by the forward pass; they are expanded on demand by this call. */
 int grl_net_read_activation(grl_net *net, const char *which, float *host, size_t bytes);
 
 /* ---- multi-GPU: one process per GPU, one RCCL all-reduce (sum, fp32) of the flat gradient per
