@@ -34,6 +34,7 @@ struct ConvOffsets {
 static_assert(ConvOffsets::total == 2210213, "parameter count (SURVEY N1)");
 
 using GatherConv2 = ConvGather<9, 9, 2, 2, 0, 0, 4, 4, 32, 20, 20, false>;    // a1[n][20][20][32] -> (n*81, 512)
+using GatherConv2Relu = ConvGather<9, 9, 2, 2, 0, 0, 4, 4, 32, 20, 20, false, true>;   // relu(sraw) -> the same operand
 using GatherConv3 = ConvGather<7, 7, 1, 1, 0, 0, 3, 3, 64, 9, 9, false>;      // a2[n][9][9][64]  -> (n*49, 576)
 // data gradients (transposed convolutions, zero-filled borders):
 using GatherT3 = ConvGather<9, 9, 1, 1, -2, -2, 3, 3, 64, 7, 7, true>;        // dz3[n][7][7][64] -> rows (n,y,x) of a2
@@ -99,6 +100,9 @@ struct grl_net {
     // not change between the two (paac.py:302-387).  keep_version tracks that; GRL_NET_F_RECOMPUTE_FORWARD or too
     // little free memory selects recomputation.
     float *ws_a3, *ws_d1, *ws_d2, *ws_p1, *ws_v1, *ws_v2, *ws_a3sh, *ws_d3, *ws_v3;   // chunk workspace (the default binding)
+    float *ws_sraw, *ws_a2sh, *ws_d2s, *ws_v2s;
+    signed char *ws_ulist;
+    int keep_level;            // 0: nothing resident, 1: conv3/dense activations, 2: + the per-env trunk tensors the gradient step reads
     float *keep;
     size_t keep_slots;
     long param_version, keep_version;
@@ -294,22 +298,25 @@ __global__ void sample_actions_kernel(const float *__restrict__ mu, const float 
 #include "net_patch.inc"
 
 // ------------------------------------------------------------------------------------------ forward pass of one chunk
-// floats kept per chunk slot: per-agent-trunk mode a3 + dense stack; shared mode a3sh (per env) + d3 + v3 + dense stack
-static size_t keep_floats_per_slot(const grl_net *net) {
+// floats kept per chunk slot: per-agent-trunk mode a3 + dense stack; shared mode a3sh (per env) + d3 + v3 + dense stack,
+// and at level 2 also what the gradient step reads of the per-env trunk: sraw, a2sh (per env), d2s, v2s, ulist (per slot)
+static size_t keep_floats_per_slot(const grl_net *net, int level) {
     const size_t c = net->chunk, dense = 512 + 256 + 512 + 512 + 256;
-    return net->shared_trunk ? (c / 10) * 3136 + c * (1600 + 1600 + dense) : c * (3136 + dense);
+    if (!net->shared_trunk) return c * (3136 + dense);
+    size_t f = (c / 10) * 3136 + c * (1600 + 1600 + dense);
+    if (level >= 2) f += (c / 10) * (12800 + 5184) + c * (576 + 576) + ((c * 9 + 3) / 4 + 3) / 4 * 4;      // stays a multiple of 16 bytes
+    return f;
 }
 
 // the activations the gradient step reads point into slot `slot` of the rollout-resident buffer, or at the chunk
 // workspace for slot < 0
 static void bind_activations(grl_net *net, long slot) {
-    if (slot < 0 || !net->keep) {
-        net->a3 = net->ws_a3; net->d1 = net->ws_d1; net->d2 = net->ws_d2; net->p1 = net->ws_p1; net->v1 = net->ws_v1; net->v2 = net->ws_v2;
-        net->a3sh = net->ws_a3sh; net->d3 = net->ws_d3; net->v3 = net->ws_v3;
-        return;
-    }
+    net->a3 = net->ws_a3; net->d1 = net->ws_d1; net->d2 = net->ws_d2; net->p1 = net->ws_p1; net->v1 = net->ws_v1; net->v2 = net->ws_v2;
+    net->a3sh = net->ws_a3sh; net->d3 = net->ws_d3; net->v3 = net->ws_v3;
+    net->sraw = net->ws_sraw; net->a2sh = net->ws_a2sh; net->d2s = net->ws_d2s; net->v2s = net->ws_v2s; net->ulist = net->ws_ulist;
+    if (slot < 0 || !net->keep) return;
     const size_t c = net->chunk;
-    float *b = net->keep + (size_t)slot * keep_floats_per_slot(net);
+    float *b = net->keep + (size_t)slot * keep_floats_per_slot(net, net->keep_level);
     if (net->shared_trunk) {
         net->a3sh = b; b += (c / 10) * 3136;
         net->d3 = b; b += c * 1600;
@@ -321,7 +328,14 @@ static void bind_activations(grl_net *net, long slot) {
     net->d2 = b; b += c * 256;
     net->p1 = b; b += c * 512;
     net->v1 = b; b += c * 512;
-    net->v2 = b;
+    net->v2 = b; b += c * 256;
+    if (net->shared_trunk && net->keep_level >= 2) {
+        net->sraw = b; b += (c / 10) * 12800;
+        net->a2sh = b; b += (c / 10) * 5184;
+        net->d2s = b; b += c * 576;
+        net->v2s = b; b += c * 576;
+        net->ulist = reinterpret_cast<signed char *>(b);
+    }
 }
 
 // reuse_tail: a3..v2 of this chunk are already resident (bind_activations); only the cheap per-env trunk, the
@@ -333,7 +347,8 @@ static int forward_chunk(grl_net *net, const uint8_t *lb, const uint8_t *ab, con
     const int n = nenv * 10;
     net->last_n = n;
     if (net->shared_trunk) {
-        int rc = forward_conv12_shared(net, lb, ab, pos, nenv);
+        // gradient step on resident activations: at level 2 the trunk tensors are resident too, only the group sort reruns
+        int rc = reuse_tail && net->keep_level >= 2 ? patch_sort(net, n) : forward_conv12_shared(net, lb, ab, pos, nenv);
         if (rc) return rc;
     } else {
     hipLaunchKernelGGL(conv1_sparse_kernel, dim3(nenv), dim3(256), 0, st, lb, ab, pos, P + ConvOffsets::c1w, P + ConvOffsets::c1b,
@@ -437,6 +452,7 @@ int grl_net_create(grl_handle *h, const grl_net_config *cfg, grl_net **out) {
     n->T = 0; n->B = 0; n->tmp_envs = 0; n->act_counter = 0; n->prof_on = false; n->prof_used = 0; n->prof_flops = 0; n->last_n = 0;
     n->ro_lb = nullptr; n->slab = nullptr; n->slab_floats = 0; n->slab64 = nullptr; n->w3t = n->w2t = nullptr;
     n->ga1 = nullptr; n->mu = n->sigma = n->vs = nullptr;
+    n->keep_level = 0;
     n->keep = nullptr; n->keep_slots = 0; n->param_version = 0; n->keep_version = -1;
     size_t c = n->chunk;
     int rc = GRL_OK;
@@ -452,6 +468,7 @@ int grl_net_create(grl_handle *h, const grl_net_config *cfg, grl_net **out) {
     n->ptiles = (int)((c + 255) / 256) + 9;
     A(&n->a3sh, (c / 10) * 3136); A(&n->d3, c * 1600); A(&n->v3, c * 1600); A(&n->ysh, (c / 10) * 512);
     n->ws_a3sh = n->a3sh; n->ws_d3 = n->d3; n->ws_v3 = n->v3;
+    n->ws_sraw = n->sraw; n->ws_a2sh = n->a2sh; n->ws_d2s = n->d2s; n->ws_v2s = n->v2s; n->ws_ulist = n->ulist;
     if (rc == GRL_OK) rc = nalloc(n, &n->perm, (size_t)n->ptiles * 256);
     if (rc == GRL_OK) rc = nalloc(n, &n->goffp, 16);
     n->pslices = (int)((c + 1023) / 1024) + 9;

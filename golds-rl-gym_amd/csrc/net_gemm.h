@@ -31,10 +31,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // Row r of the (virtual) operand = output pixel (n, qy, qx); reduction index k = ((ty*P + tx)*C + c)
 // reads src[n][iy0+ty][ix0+tx][c] with (iy0, ix0) = (qy*SY + OY0, qx*SX + OX0) in an NHWC tensor
 // [n][H][W][C].  CHECK=true zero-fills taps outside the image (transposed convolutions).
-template <int QH, int QW, int SY, int SX, int OY0, int OX0, int S, int P, int C, int H, int W, bool CHECK>
+// RELU=true: the operand is relu(src) (gemm_tn only: conv2's weight gradient reads a1sh = relu(sraw) from the pre-activation)
+template <int QH, int QW, int SY, int SX, int OY0, int OX0, int S, int P, int C, int H, int W, bool CHECK, bool RELU = false>
 struct ConvGather {
     static constexpr int kPPS = QH * QW;
     static constexpr int kC = C;
+    static constexpr bool kRelu = RELU;
     const float *base;
     int rows;
     __device__ __forceinline__ int K() const { return S * P * C; }
@@ -72,6 +74,7 @@ struct ConvGather {
 // (conv3's data gradient: 441 of 729 (pixel, tap) combinations are inside).
 template <int QH, int QW, int OY0, int OX0, int S, int P, int C, int H, int W>
 struct ConvGatherPM {
+    static constexpr bool kRelu = false;
     const float *base;
     int rows, nsamp;
     __device__ __forceinline__ int K() const { return S * P * C; }
@@ -109,6 +112,7 @@ struct ConvGatherPM {
 // row r = (sample n = r/9, slot r%9) with pixel u = ulist[r] of the 9x9 map (or -1: empty slot, all taps invalid);
 // k = (ty, tx, co) reads dz3[n][uy-2+ty][ux-2+tx][co] like ConvGather<9,9,1,1,-2,-2,3,3,64,7,7,true>.
 struct SlotGatherT3 {
+    static constexpr bool kRelu = false;
     const float *base;
     const signed char *ulist;
     int rows;
@@ -140,6 +144,7 @@ struct SlotGatherT3 {
 };
 
 struct DenseRows {   // plain row-major [rows][ld], reduction length k
+    static constexpr bool kRelu = false;
     const float *base;
     int rows, ld, k;
     __device__ __forceinline__ int K() const { return k; }
@@ -164,6 +169,7 @@ struct DenseRows {   // plain row-major [rows][ld], reduction length k
 // Same on the patch-compact per-agent dz3 (net_patch.inc): base[n][py][px][co] (5x5 window with origin org[n] = oy*3+ox);
 // every pixel u - 2 + t inside the 7x7 map lies inside the agent's window by construction.
 struct SlotGatherT3P {
+    static constexpr bool kRelu = false;
     const float *base;
     const signed char *ulist, *org;
     int rows;
@@ -201,6 +207,7 @@ struct SlotGatherT3P {
 //   mode 0: the reduction runs over the patch (forward, weight gradient): B's k offset is remapped per 320-float strip
 //   mode 1: the output columns are the patch (data gradient): B's row base is remapped per 64-column tile (one pixel)
 struct PatchRows {
+    static constexpr bool kRelu = false;
     const float *base;
     const int *perm;
     const signed char *tilegroup;
@@ -517,6 +524,7 @@ __global__ __launch_bounds__(256) void gemm_tn(AG ag, const float *__restrict__ 
             const bool v = (vma >> i) & 1u;                                                                        \
             float4 t4 = ra[i];                                                                                     \
             t4.x = v ? t4.x : 0.f; t4.y = v ? t4.y : 0.f; t4.z = v ? t4.z : 0.f; t4.w = v ? t4.w : 0.f;            \
+            if (AG::kRelu) { t4.x = fmaxf(t4.x, 0.f); t4.y = fmaxf(t4.y, 0.f); t4.z = fmaxf(t4.z, 0.f); t4.w = fmaxf(t4.w, 0.f); } \
             *reinterpret_cast<float4 *>(As + (tid + 256 * i) * 4) = t4;                                            \
         }                                                                                                          \
         _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                           \
