@@ -233,7 +233,7 @@ def test_resident_rollout_activations_equal_recomputation():
     second update checks that the kept activations are refreshed after the parameters moved."""
     out = []
     for flags in (0, 2):
-        eng, net, p, states, obs = _setup(12, flags=flags)       # 120 samples, chunks of 40 -> 3 slots per step
+        eng, net, p, states, obs = _setup(10, flags=flags)       # 100 samples, chunks of 40, 40 and a ragged 20 -> 3 slots per step
         res = []
         for _ in range(2):
             net.rollout(3, 0)
