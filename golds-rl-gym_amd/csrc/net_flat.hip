@@ -4,12 +4,11 @@
 // obs transform of a3c/worker.py:420-431, tanh actions :440-442, hyper-parameters of scripts/train_trade.py:38-40,119).
 //
 // The net has ~31k parameters and a few tens of kMAC per sample; BASELINE config 2 (4 096 envs) is
-// launch/latency bound, so the design goal is FEW LAUNCHES, not MFMA: one lane per sample,
-// one wave per workgroup, the whole forward (5 GRU steps + 13 dense layers) in ONE launch and the whole
-// backward in one more.  Activations of the wave's 64 samples are staged in LDS as [feature][lane]
-// (row stride 65 => conflict-free both for a lane reading its own column and for the weight-gradient
-// dot products along a row); weights are wave-uniform (scalar loads).  Weight gradients are summed per
-// workgroup into private slabs and reduced in a fixed order (bitwise reproducible).
+// launch/latency bound, so the whole forward (5 GRU steps + 13 dense layers) is ONE launch and the
+// whole backward one more.  A workgroup of 4 waves owns 64 samples; activations are staged in LDS as
+// [feature][sample] (row stride 65) and every dense layer and every gradient is a small fp32 MFMA GEMM against
+// those rows (net_flat_mfma.inc).  Weight gradients are summed per workgroup into private slabs and reduced in
+// a fixed order (bitwise reproducible).
 #include <string.h>
 
 #include <cmath>
@@ -80,321 +79,7 @@ struct FlatArgs {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-// acc[o] = b[o] + sum_i xin[i][lane] * W[i][o]      (W wave-uniform -> scalar loads)
-template <int N>
-__device__ __forceinline__ void dense_fwd(const float *__restrict__ W, const float *__restrict__ b, const float *xin, int K, int lane,
-                                          float (&acc)[N]) {
-#pragma unroll
-    for (int o = 0; o < N; ++o) acc[o] = b[o];
-    for (int i = 0; i < K; ++i) {
-        const float a = xin[i * LS + lane];
-        const float *w = W + (long)i * N;
-#pragma unroll
-        for (int o = 0; o < N; ++o) acc[o] = __builtin_fmaf(a, w[o], acc[o]);
-    }
-}
-
-__device__ __forceinline__ float dense_fwd1(const float *__restrict__ W, float b, const float *xin, int K, int ldw, int col, int lane) {
-    float acc = b;
-    for (int i = 0; i < K; ++i) acc = __builtin_fmaf(xin[i * LS + lane], W[(long)i * ldw + col], acc);
-    return acc;
-}
-
-constexpr int FLAT_LDS_ROWS = 96 + 96 + 65 + 64 + 65;     // bufX, bufC, bufA, bufB, bufT
-constexpr size_t FLAT_LDS_BYTES = (size_t)FLAT_LDS_ROWS * LS * sizeof(float);
-
-// ------------------------------------------------------------------------------------------ forward
-__global__ __launch_bounds__(64) void flat_forward_kernel(FlatArgs a) {
-    extern __shared__ float lds[];
-    float *bufX = lds, *bufA = lds + 192 * LS, *bufB = bufA + 65 * LS;
-    const int lane = threadIdx.x, s = blockIdx.x * 64 + lane;
-    const bool valid = s < a.n;
-    const int ss = valid ? s : 0;
-    const float *P = a.P;
-    const int D = a.D, T = a.T, A = a.A, n = a.n;
-    const WsOff wo = ws_offsets(T, A);
-    float *ws = a.ws;
-    const bool synth = a.nhist != nullptr;
-    const float *hrow = synth ? a.states + (long)ss * a.S0 : a.hist + (long)ss * T * D;
-    const int hstep = synth ? 0 : D;      // synthesized window: every valid row is the current state
-    int nrows = T;
-    if (synth) { int nh = a.nhist[ss]; nh = nh < 1 ? 1 : nh; nrows = nh < T ? nh : T; }
-    // true_length (a3c/estimators.py:11-15): number of rows with a non-zero entry
-    int len = 0;
-    for (int t = 0; t < T; ++t) {
-        float m = 0.f;
-        for (int i = 0; i < D; ++i) m = fmaxf(m, fabsf(t < nrows ? hrow[t * hstep + i] : 0.f));
-        len += m > 0.f ? 1 : 0;
-    }
-    float h[FH];
-#pragma unroll
-    for (int i = 0; i < FH; ++i) h[i] = 0.f;
-    for (int t = 0; t < T; ++t) {
-        // GRUCell (TF 1.4): r,u = sigmoid([x,h] Wg + bg); c = tanh([x, r*h] Wc + bc); h' = u*h + (1-u)*c
-        for (int i = 0; i < D; ++i) bufA[i * LS + lane] = t < nrows ? hrow[t * hstep + i] : 0.f;
-#pragma unroll
-        for (int i = 0; i < FH; ++i) bufA[(D + i) * LS + lane] = h[i];
-        float g[2 * FH];
-        dense_fwd<2 * FH>(P + a.o.gw, P + a.o.gb, bufA, D + FH, lane, g);
-#pragma unroll
-        for (int i = 0; i < 2 * FH; ++i) g[i] = sigmoidf_(g[i]);
-#pragma unroll
-        for (int i = 0; i < FH; ++i) bufA[(D + i) * LS + lane] = g[i] * h[i];
-        float c[FH];
-        dense_fwd<FH>(P + a.o.cw, P + a.o.cb, bufA, D + FH, lane, c);
-        const bool act = t < len;       // dynamic_rnn(sequence_length): the state is copied through past the end
-#pragma unroll
-        for (int i = 0; i < FH; ++i) {
-            c[i] = tanhf(c[i]);
-            if (ws && valid) {
-                ws[(long)(ws_step(t) + i) * n + s] = h[i];
-                ws[(long)(ws_step(t) + FH + i) * n + s] = g[i];
-                ws[(long)(ws_step(t) + 2 * FH + i) * n + s] = g[FH + i];
-                ws[(long)(ws_step(t) + 3 * FH + i) * n + s] = c[i];
-            }
-            if (act) h[i] = g[FH + i] * h[i] + (1.0f - g[FH + i]) * c[i];
-        }
-    }
-    // rnn_graph_lstm (a3c/estimators.py:24-28): dense_temporal, dense_static x2, concat
-#pragma unroll
-    for (int i = 0; i < FH; ++i) {
-        bufA[i * LS + lane] = h[i];
-        if (ws && valid) ws[(long)(wo.hl + i) * n + s] = h[i];
-    }
-    {
-        float d[2 * FH];
-        dense_fwd<2 * FH>(P + a.o.tw, P + a.o.tb, bufA, FH, lane, d);
-#pragma unroll
-        for (int i = 0; i < 2 * FH; ++i) {
-            d[i] = fmaxf(d[i], 0.f);
-            bufX[i * LS + lane] = d[i];
-            if (ws && valid) ws[(long)(wo.dt + i) * n + s] = d[i];
-        }
-    }
-    for (int i = 0; i < a.S0; ++i) bufB[i * LS + lane] = a.states[(long)ss * a.S0 + i];
-    {
-        float s1[2 * FH];
-        dense_fwd<2 * FH>(P + a.o.s1w, P + a.o.s1b, bufB, a.S0, lane, s1);
-#pragma unroll
-        for (int i = 0; i < 2 * FH; ++i) {
-            s1[i] = fmaxf(s1[i], 0.f);
-            bufA[i * LS + lane] = s1[i];
-            if (ws && valid) ws[(long)(wo.s1 + i) * n + s] = s1[i];
-        }
-        float s2[FH];
-        dense_fwd<FH>(P + a.o.s2w, P + a.o.s2b, bufA, 2 * FH, lane, s2);
-#pragma unroll
-        for (int i = 0; i < FH; ++i) {
-            s2[i] = fmaxf(s2[i], 0.f);
-            bufX[(2 * FH + i) * LS + lane] = s2[i];
-            if (ws && valid) ws[(long)(wo.s2 + i) * n + s] = s2[i];
-        }
-    }
-    // mu / sigma heads (policy_v_network.py:214-226) -- two hidden layers each
-    for (int head = 0; head < 2; ++head) {
-        const long w1 = head ? a.o.g1w : a.o.m1w, b1 = head ? a.o.g1b : a.o.m1b, w2 = head ? a.o.g2w : a.o.m2w,
-                   b2 = head ? a.o.g2b : a.o.m2b, w3 = head ? a.o.g3w : a.o.m3w, b3 = head ? a.o.g3b : a.o.m3b;
-        const int o1 = head ? wo.g1 : wo.m1, o2 = head ? wo.g2 : wo.m2, o3 = head ? wo.sg : wo.tm;
-        float l1[2 * FH];
-        dense_fwd<2 * FH>(P + w1, P + b1, bufX, 3 * FH, lane, l1);
-#pragma unroll
-        for (int i = 0; i < 2 * FH; ++i) {
-            l1[i] = fmaxf(l1[i], 0.f);
-            bufA[i * LS + lane] = l1[i];
-            if (ws && valid) ws[(long)(o1 + i) * n + s] = l1[i];
-        }
-        float l2[FH];
-        dense_fwd<FH>(P + w2, P + b2, bufA, 2 * FH, lane, l2);
-#pragma unroll
-        for (int i = 0; i < FH; ++i) {
-            l2[i] = tanhf(l2[i]);
-            bufB[i * LS + lane] = l2[i];
-            if (ws && valid) ws[(long)(o2 + i) * n + s] = l2[i];
-        }
-        for (int k = 0; k < A; ++k) {
-            float z = dense_fwd1(P + w3, P[b3 + k], bufB, FH, A, k, lane);
-            float v = head ? sigmoidf_(z) : tanhf(z);
-            if (ws && valid) ws[(long)(o3 + k) * n + s] = v;
-            if (valid) {
-                if (head) a.sigma[(long)s * A + k] = v + 1e-3f;      // sigmoid(.) + 1e-3 (:223-226)
-                else a.mu[(long)s * A + k] = a.bound * v;           // ((ub-lb)/2)*tanh + (lb+ub)/2 with lb = -ub (:219)
-            }
-        }
-    }
-    // value head (:237-244): scale * Dense1(tanh(Dense64(x)))
-    {
-        float v1[2 * FH];
-        dense_fwd<2 * FH>(P + a.o.v1w, P + a.o.v1b, bufX, 3 * FH, lane, v1);
-#pragma unroll
-        for (int i = 0; i < 2 * FH; ++i) {
-            v1[i] = tanhf(v1[i]);
-            bufA[i * LS + lane] = v1[i];
-            if (ws && valid) ws[(long)(wo.v1 + i) * n + s] = v1[i];
-        }
-        float z = dense_fwd1(P + a.o.v2w, P[a.o.v2b], bufA, 2 * FH, 1, 0, lane);
-        float v = a.scale * z;
-        if (valid) a.vs[s] = v;
-        if (ws && valid) ws[(long)wo.vs * n + s] = v;
-    }
-}
-
-// ------------------------------------------------------------------------------------------ backward
-// dz rows in dzl[N][LS] (all lanes), forward input rows in xin[K][LS].  Adds this group's contribution
-// to the block's private gradient slab; optionally produces dx rows for the lane's own sample.
-__device__ __forceinline__ void dense_bwd(const float *__restrict__ W, int K, int N, const float *xin, const float *dzl, float *dxl,
-                                          bool accumulate_dx, float *gW, float *gb, int lane) {
-    __syncthreads();
-    for (int w = lane; w < K * N; w += 64) {
-        const int i = w / N, o = w - i * N;
-        const float *xr = xin + i * LS, *zr = dzl + o * LS;
-        float sum = 0.f;
-#pragma unroll 8
-        for (int q = 0; q < 64; ++q) sum = __builtin_fmaf(xr[q], zr[q], sum);
-        gW[w] += sum;
-    }
-    for (int o = lane; o < N; o += 64) {
-        const float *zr = dzl + o * LS;
-        float sum = 0.f;
-        for (int q = 0; q < 64; ++q) sum += zr[q];
-        gb[o] += sum;
-    }
-    if (dxl) {
-        for (int i = 0; i < K; ++i) {
-            const float *w = W + (long)i * N;
-            float sum = 0.f;
-            for (int o = 0; o < N; ++o) sum = __builtin_fmaf(w[o], dzl[o * LS + lane], sum);
-            if (accumulate_dx) dxl[i * LS + lane] += sum;
-            else dxl[i * LS + lane] = sum;
-        }
-    }
-    __syncthreads();
-}
-
-__device__ __forceinline__ float wave_sum_f(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-
-__global__ __launch_bounds__(64) void flat_backward_kernel(FlatArgs a) {
-    extern __shared__ float lds[];
-    float *bufX = lds, *bufC = lds + 96 * LS, *bufA = lds + 192 * LS, *bufB = bufA + 65 * LS, *bufT = bufB + 64 * LS;
-    const int lane = threadIdx.x;
-    const float *P = a.P;
-    const int D = a.D, T = a.T, A = a.A, n = a.n;
-    const WsOff wo = ws_offsets(T, A);
-    const float *ws = a.ws;
-    float *G = a.slab + (long)blockIdx.x * a.o.total;
-    const int groups = (n + 63) / 64;
-    float loss_p = 0.f, loss_c = 0.f;
-    for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {
-        const int s = grp * 64 + lane;
-        const bool valid = s < n;
-        const int ss = valid ? s : 0;
-        auto W = [&](int f) { return valid ? ws[(long)f * n + ss] : 0.f; };
-        __syncthreads();
-        // ---- loss terms (policy_v_network.py:228-251): mean over (n, A) of -logp*adv; mean over n of 0.25*(vs-y)^2/scale
-        const float advs = valid ? a.adv[ss] : 0.f, tgt = valid ? a.y[ss] : 0.f, vsv = W(wo.vs);
-        const float dlogp = -advs * a.inv_n / (float)A;
-        const float dvs = valid ? 0.5f * (vsv - tgt) / a.scale * a.inv_n : 0.f;
-        if (valid) loss_c += 0.25f * (vsv - tgt) * (vsv - tgt) / a.scale;
-        for (int head = 0; head < 2; ++head) {
-            const long w1 = head ? a.o.g1w : a.o.m1w, b1 = head ? a.o.g1b : a.o.m1b, w2 = head ? a.o.g2w : a.o.m2w,
-                       b2 = head ? a.o.g2b : a.o.m2b, w3 = head ? a.o.g3w : a.o.m3w, b3 = head ? a.o.g3b : a.o.m3b;
-            const int o1 = head ? wo.g1 : wo.m1, o2 = head ? wo.g2 : wo.m2;
-            for (int k = 0; k < A; ++k) {
-                const float tm = W(wo.tm + k), sg = W(wo.sg + k);
-                const float mu = a.bound * tm, sigma = sg + 1e-3f;
-                const float act = valid ? a.actions[(long)ss * A + k] : mu;
-                const float diff = act - mu;
-                float dz;
-                if (head == 0) {
-                    dz = dlogp * diff / (sigma * sigma) * a.bound * (1.0f - tm * tm);
-                    if (valid) loss_p += -(-0.5f * (diff / sigma) * (diff / sigma) - logf(sigma) - 0.9189385332046727f) * advs;
-                } else {
-                    dz = dlogp * (diff * diff / (sigma * sigma * sigma) - 1.0f / sigma) * sg * (1.0f - sg);
-                }
-                bufB[k * LS + lane] = valid ? dz : 0.f;
-            }
-            for (int i = 0; i < FH; ++i) bufA[i * LS + lane] = W(o2 + i);
-            dense_bwd(P + w3, FH, A, bufA, bufB, bufT, false, G + w3, G + b3, lane);
-            for (int i = 0; i < FH; ++i) { float m2 = bufA[i * LS + lane]; bufB[i * LS + lane] = bufT[i * LS + lane] * (1.0f - m2 * m2); }
-            for (int i = 0; i < 2 * FH; ++i) bufA[i * LS + lane] = W(o1 + i);
-            dense_bwd(P + w2, 2 * FH, FH, bufA, bufB, bufT, false, G + w2, G + b2, lane);
-            for (int i = 0; i < 2 * FH; ++i) bufB[i * LS + lane] = bufA[i * LS + lane] > 0.f ? bufT[i * LS + lane] : 0.f;
-            if (head == 0) {
-                for (int i = 0; i < 2 * FH; ++i) bufX[i * LS + lane] = W(wo.dt + i);
-                for (int i = 0; i < FH; ++i) bufX[(2 * FH + i) * LS + lane] = W(wo.s2 + i);
-            }
-            dense_bwd(P + w1, 3 * FH, 2 * FH, bufX, bufB, bufC, head != 0, G + w1, G + b1, lane);
-        }
-        // ---- value head
-        bufB[lane] = dvs * a.scale;
-        for (int i = 0; i < 2 * FH; ++i) bufA[i * LS + lane] = W(wo.v1 + i);
-        dense_bwd(P + a.o.v2w, 2 * FH, 1, bufA, bufB, bufT, false, G + a.o.v2w, G + a.o.v2b, lane);
-        for (int i = 0; i < 2 * FH; ++i) { float v1 = bufA[i * LS + lane]; bufB[i * LS + lane] = bufT[i * LS + lane] * (1.0f - v1 * v1); }
-        dense_bwd(P + a.o.v1w, 3 * FH, 2 * FH, bufX, bufB, bufC, true, G + a.o.v1w, G + a.o.v1b, lane);
-        // ---- trunk: bufC holds d x96 = [d dense_temporal (64), d dense_static (32)]
-        for (int i = 0; i < FH; ++i) bufB[i * LS + lane] = bufX[(2 * FH + i) * LS + lane] > 0.f ? bufC[(2 * FH + i) * LS + lane] : 0.f;
-        for (int i = 0; i < 2 * FH; ++i) bufA[i * LS + lane] = W(wo.s1 + i);
-        dense_bwd(P + a.o.s2w, 2 * FH, FH, bufA, bufB, bufT, false, G + a.o.s2w, G + a.o.s2b, lane);
-        for (int i = 0; i < 2 * FH; ++i) bufB[i * LS + lane] = bufA[i * LS + lane] > 0.f ? bufT[i * LS + lane] : 0.f;
-        __syncthreads();
-        for (int i = 0; i < a.S0; ++i) bufA[i * LS + lane] = valid ? a.states[(long)ss * a.S0 + i] : 0.f;
-        dense_bwd(P + a.o.s1w, a.S0, 2 * FH, bufA, bufB, nullptr, false, G + a.o.s1w, G + a.o.s1b, lane);
-        for (int i = 0; i < 2 * FH; ++i) bufB[i * LS + lane] = bufX[i * LS + lane] > 0.f ? bufC[i * LS + lane] : 0.f;
-        for (int i = 0; i < FH; ++i) bufA[i * LS + lane] = W(wo.hl + i);
-        dense_bwd(P + a.o.tw, FH, 2 * FH, bufA, bufB, bufT, false, G + a.o.tw, G + a.o.tb, lane);
-        float dh[FH], keep[FH];
-#pragma unroll
-        for (int i = 0; i < FH; ++i) dh[i] = bufT[i * LS + lane];
-        // ---- GRU, back through time with the sequence-length mask
-        const bool synth = a.nhist != nullptr;
-        const float *hrow = synth ? a.states + (long)ss * a.S0 : a.hist + (long)ss * T * D;
-        const int hstep = synth ? 0 : D;
-        int nrows = T;
-        if (synth) { int nh = a.nhist[ss]; nh = nh < 1 ? 1 : nh; nrows = nh < T ? nh : T; }
-        int len = 0;
-        for (int t = 0; t < T; ++t) {
-            float m = 0.f;
-            for (int i = 0; i < D; ++i) m = fmaxf(m, fabsf(t < nrows ? hrow[t * hstep + i] : 0.f));
-            len += (valid && m > 0.f) ? 1 : 0;
-        }
-        for (int t = T - 1; t >= 0; --t) {
-            const bool act = t < len;
-            __syncthreads();
-            for (int i = 0; i < D; ++i) bufA[i * LS + lane] = (valid && t < nrows) ? hrow[t * hstep + i] : 0.f;
-#pragma unroll
-            for (int i = 0; i < FH; ++i) {
-                const float hp = W(ws_step(t) + i), r = W(ws_step(t) + FH + i), u = W(ws_step(t) + 2 * FH + i), c = W(ws_step(t) + 3 * FH + i);
-                const float dhn = act ? dh[i] : 0.f;
-                keep[i] = dhn * u;
-                bufB[i * LS + lane] = dhn * (1.0f - u) * (1.0f - c * c);             // dz of the candidate
-                bufB[(FH + i) * LS + lane] = dhn * (hp - c) * u * (1.0f - u);         // dz of the update gate (kept for later)
-                bufA[(D + i) * LS + lane] = r * hp;
-            }
-            dense_bwd(P + a.o.cw, D + FH, FH, bufA, bufB, bufT, false, G + a.o.cw, G + a.o.cb, lane);
-#pragma unroll
-            for (int i = 0; i < FH; ++i) {
-                const float hp = W(ws_step(t) + i), r = W(ws_step(t) + FH + i);
-                const float drh = bufT[(D + i) * LS + lane];
-                keep[i] += drh * r;
-                bufB[i * LS + lane] = drh * hp * r * (1.0f - r);                     // dz of the reset gate
-                bufA[(D + i) * LS + lane] = hp;
-            }
-            dense_bwd(P + a.o.gw, D + FH, 2 * FH, bufA, bufB, bufT, false, G + a.o.gw, G + a.o.gb, lane);
-#pragma unroll
-            for (int i = 0; i < FH; ++i)
-                if (act) dh[i] = keep[i] + bufT[(D + i) * LS + lane];
-        }
-    }
-    loss_p = wave_sum_f(loss_p);
-    loss_c = wave_sum_f(loss_c);
-    if (lane == 0) {
-        atomicAdd(&a.stats64[0], (double)loss_p);
-        atomicAdd(&a.stats64[1], (double)loss_c);
-    }
-}
+#include "net_flat_mfma.inc"
 
 __global__ void flat_slab_reduce_kernel(const float *__restrict__ slab, int blocks, long n, float *__restrict__ dst) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -514,7 +199,7 @@ static FlatArgs base_args(grl_fnet *net, int n, const float *states, const float
 static int launch_forward(grl_fnet *net, int n, const float *states, const float *hist, float *mu, float *sigma, float *vs, bool save,
                           const int32_t *nhist = nullptr) {
     FlatArgs a = base_args(net, n, states, hist, mu, sigma, vs, save, nhist);
-    hipLaunchKernelGGL(flat_forward_kernel, dim3((n + 63) / 64), dim3(64), FLAT_LDS_BYTES, net->h->stream, a);
+    hipLaunchKernelGGL(flat_forward_kernel, dim3((n + 63) / 64), dim3(256), FLAT_LDS_BYTES, net->h->stream, a);
     FNET_HIP(net, hipGetLastError());
     return GRL_OK;
 }
@@ -532,7 +217,7 @@ static int train_device(grl_fnet *net, int n, const float *states, const float *
     FNET_HIP(net, hipMemsetAsync(net->stats64, 0, 4 * sizeof(double), st));
     FlatArgs a = base_args(net, n, states, hist, net->mu, net->sigma, net->vs, true, nhist);
     a.actions = actions; a.adv = adv; a.y = y; a.inv_n = 1.0f / (float)n; a.slab = net->slab; a.stats64 = net->stats64;
-    hipLaunchKernelGGL(flat_backward_kernel, dim3(blocks), dim3(64), FLAT_LDS_BYTES, st, a);
+    hipLaunchKernelGGL(flat_backward_kernel, dim3(blocks), dim3(256), FLAT_LDS_BYTES, st, a);
     hipLaunchKernelGGL(flat_slab_reduce_kernel, dim3((unsigned)((net->off.total + 255) / 256)), dim3(256), 0, st, net->slab, blocks,
                        net->off.total, net->grads);
     hipLaunchKernelGGL(flat_sumsq_kernel, dim3(1), dim3(256), 0, st, net->grads, net->off.total, net->stats64 + 2);
