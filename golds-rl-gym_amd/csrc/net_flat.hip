@@ -124,9 +124,12 @@ __global__ void flat_adam_kernel(float *__restrict__ p, const float *__restrict_
 
 // a = mu + sigma*N(0,1) (paac.py:36), SolowRunner.transform_actions_for_env = sigmoid (emulator_runner.py:77-79)
 __global__ void flat_sample_kernel(const float *__restrict__ mu, const float *__restrict__ sigma, int n, int A, uint64_t seed,
-                                   uint32_t env_off, uint32_t counter, int env_kind, float *__restrict__ raw, float *__restrict__ envact) {
+                                   uint32_t env_off, const uint32_t *__restrict__ counter_base, uint32_t step, int env_kind,
+                                   float *__restrict__ raw, float *__restrict__ envact) {
+    // the draw counter is read from device memory so that a captured rollout graph can be replayed (base is set per rollout)
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n * A) return;
+    const uint32_t counter = *counter_base + step;
     int e = i / A, k = i - e * A;
     double e0, e1;
     normal_pair(rng_block(seed, (uint32_t)e + env_off, counter, RS_FLAT_ACTION, k >> 1), e0, e1);
@@ -164,6 +167,9 @@ struct grl_fnet {
     float *ro_states, *ro_hist, *ro_act, *ro_envact, *ro_val, *ro_rew, *ro_mask, *ro_y, *ro_adv, *ro_boot;
     int32_t *ro_nhist;
     unsigned long act_counter;
+    uint32_t *d_counter;           // act_counter at the start of the rollout in flight
+    hipGraphExec_t ro_graph;       // the T-step rollout captured once and replayed (launch-bound at 4 096 envs)
+    int ro_graph_T;
     std::vector<void *> allocs;
 };
 
@@ -239,6 +245,44 @@ static int train_device(grl_fnet *net, int n, const float *states, const float *
     return GRL_OK;
 }
 
+// the T-step actor loop as stream operations (captured into a graph by grl_fnet_rollout)
+static int enqueue_rollout(grl_fnet *net, int T) {
+    grl_handle *h = net->h;
+    const bool solow = h->cfg.env_kind == GRL_ENV_SOLOW;
+    const int E = h->E, R = net->cfg.rnn_length, S0 = net->cfg.static_size, A = net->cfg.num_actions;
+    hipStream_t st = h->stream;
+    const float *obs = solow ? h->so.obs : h->tr.obs;
+    int rc;
+    for (int t = 0; t < T; ++t) {
+        // states[t] = shared_states, histories[t] = shared_histories (paac.py:132-133).  For TradeAR1 the window is
+        // kept as (state, #rows): the worker's history is min(n, rnn) copies of the current state (quirk Q11)
+        FNET_HIP(net, hipMemcpyAsync(net->ro_states + (size_t)t * E * S0, obs, (size_t)E * S0 * 4, hipMemcpyDeviceToDevice, st));
+        if (solow) {
+            FNET_HIP(net, hipMemcpyAsync(net->ro_hist + (size_t)t * E * R * 2, h->so.history, (size_t)E * R * 8, hipMemcpyDeviceToDevice, st));
+            rc = launch_forward(net, E, obs, h->so.history, net->mu, net->sigma, net->ro_val + (size_t)t * E, false);
+        } else {
+            FNET_HIP(net, hipMemcpyAsync(net->ro_nhist + (size_t)t * E, h->tr.nhist, (size_t)E * 4, hipMemcpyDeviceToDevice, st));
+            rc = launch_forward(net, E, obs, nullptr, net->mu, net->sigma, net->ro_val + (size_t)t * E, false, h->tr.nhist);
+        }
+        if (rc) return rc;
+        hipLaunchKernelGGL(flat_sample_kernel, dim3((E * A + 255) / 256), dim3(256), 0, st, net->mu, net->sigma, E, A, h->cfg.seed,
+                           (uint32_t)h->cfg.env_id_offset, (const uint32_t *)net->d_counter, (uint32_t)t, h->cfg.env_kind,
+                           net->ro_act + (size_t)t * E * A, net->ro_envact);
+        rc = solow ? solow_launch_step(h, net->ro_envact) : trade_launch_step(h, net->ro_envact);
+        if (rc) return ffail(net, rc, h->err);
+        FNET_HIP(net, hipMemcpyAsync(net->ro_rew + (size_t)t * E, h->reward, (size_t)E * 4, hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(flat_mask_kernel, dim3((E + 255) / 256), dim3(256), 0, st, h->done, E, net->ro_mask + (size_t)t * E);
+    }
+    rc = solow ? launch_forward(net, E, obs, h->so.history, net->mu, net->sigma, net->ro_boot, false)
+               : launch_forward(net, E, obs, nullptr, net->mu, net->sigma, net->ro_boot, false, h->tr.nhist);
+    if (rc) return rc;
+    // rewards clipped to [-2, 2] (paac.py:145), masked n-step return (paac.py:167-172), adv / scale (paac.py:177)
+    if ((rc = launch_returns(h, net->ro_rew, net->ro_val, net->ro_mask, net->ro_boot, T, E, net->cfg.gamma, 1.0f, net->cfg.scale, -2.f, 2.f,
+                             net->ro_y, net->ro_adv)))
+        return ffail(net, rc, h->err);
+    return GRL_OK;
+}
+
 }  // namespace grl
 
 using namespace grl;
@@ -278,6 +322,8 @@ int grl_fnet_create(grl_handle *h, const grl_fnet_config *cfg, grl_fnet **out) {
     Al(&n->d_states, ms * S0); Al(&n->d_hist, ms * T * D); Al(&n->d_act, ms * A); Al(&n->d_adv, ms); Al(&n->d_y, ms);
     Al(&n->mu, ms * A); Al(&n->sigma, ms * A); Al(&n->vs, ms);
     if (rc == GRL_OK) rc = falloc(n, &n->stats64, 8);
+    if (rc == GRL_OK) rc = falloc(n, &n->d_counter, 4);
+    n->ro_graph = nullptr; n->ro_graph_T = 0;
     hipError_t e = hipSuccess;
     if (rc == GRL_OK) e = hipFuncSetAttribute((const void *)flat_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLAT_LDS_BYTES);
     if (rc == GRL_OK && e == hipSuccess)
@@ -297,6 +343,7 @@ int grl_fnet_destroy(grl_fnet *n) {
     if (!n) return GRL_OK;
     hipSetDevice(n->h->cfg.device_id);
     hipStreamSynchronize(n->h->stream);
+    if (n->ro_graph) (void)hipGraphExecDestroy(n->ro_graph);
     for (void *p : n->allocs) hipFree(p);
     delete n;
     return GRL_OK;
@@ -404,35 +451,34 @@ int grl_fnet_rollout(grl_fnet *net, int32_t T) {
     }
     net->T = T;
     hipStream_t st = h->stream;
-    const float *obs = solow ? h->so.obs : h->tr.obs;
-    for (int t = 0; t < T; ++t) {
-        // states[t] = shared_states, histories[t] = shared_histories (paac.py:132-133).  For TradeAR1 the window is
-        // kept as (state, #rows): the worker's history is min(n, rnn) copies of the current state (quirk Q11)
-        FNET_HIP(net, hipMemcpyAsync(net->ro_states + (size_t)t * E * S0, obs, (size_t)E * S0 * 4, hipMemcpyDeviceToDevice, st));
-        if (solow) {
-            FNET_HIP(net, hipMemcpyAsync(net->ro_hist + (size_t)t * E * R * 2, h->so.history, (size_t)E * R * 8, hipMemcpyDeviceToDevice, st));
-            rc = launch_forward(net, E, obs, h->so.history, net->mu, net->sigma, net->ro_val + (size_t)t * E, false);
-        } else {
-            FNET_HIP(net, hipMemcpyAsync(net->ro_nhist + (size_t)t * E, h->tr.nhist, (size_t)E * 4, hipMemcpyDeviceToDevice, st));
-            rc = launch_forward(net, E, obs, nullptr, net->mu, net->sigma, net->ro_val + (size_t)t * E, false, h->tr.nhist);
+    // draw counter of step t = act_counter + t, read by the sample kernel from device memory
+    FNET_HIP(net, hipMemsetD32Async((hipDeviceptr_t)net->d_counter, (int)(uint32_t)net->act_counter, 1, st));
+    net->act_counter += (unsigned long)T;
+    if (net->ro_graph && net->ro_graph_T == T) {
+        FNET_HIP(net, hipGraphLaunch(net->ro_graph, st));
+    } else {
+        if (net->ro_graph) { (void)hipGraphExecDestroy(net->ro_graph); net->ro_graph = nullptr; }
+        // ~9 tiny operations per step: capture them once into a graph; every argument is a device pointer or a constant
+        const bool capturing = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
+        if (!capturing) (void)hipGetLastError();
+        rc = enqueue_rollout(net, T);
+        if (capturing) {
+            hipGraph_t graph = nullptr;
+            hipError_t e = hipStreamEndCapture(st, &graph);
+            if (rc == GRL_OK && e == hipSuccess && graph && hipGraphInstantiate(&net->ro_graph, graph, nullptr, nullptr, 0) == hipSuccess) {
+                net->ro_graph_T = T;
+            } else {
+                net->ro_graph = nullptr;
+                (void)hipGetLastError();
+            }
+            if (graph) (void)hipGraphDestroy(graph);
+            if (rc) return rc;
+            if (net->ro_graph) FNET_HIP(net, hipGraphLaunch(net->ro_graph, st));
+            else if ((rc = enqueue_rollout(net, T))) return rc;      // capture unavailable: plain launches
+        } else if (rc) {
+            return rc;
         }
-        if (rc) return rc;
-        hipLaunchKernelGGL(flat_sample_kernel, dim3((E * A + 255) / 256), dim3(256), 0, st, net->mu, net->sigma, E, A, h->cfg.seed,
-                           (uint32_t)h->cfg.env_id_offset, (uint32_t)net->act_counter, h->cfg.env_kind, net->ro_act + (size_t)t * E * A,
-                           net->ro_envact);
-        net->act_counter += 1;
-        rc = solow ? solow_launch_step(h, net->ro_envact) : trade_launch_step(h, net->ro_envact);
-        if (rc) return ffail(net, rc, h->err);
-        FNET_HIP(net, hipMemcpyAsync(net->ro_rew + (size_t)t * E, h->reward, (size_t)E * 4, hipMemcpyDeviceToDevice, st));
-        hipLaunchKernelGGL(flat_mask_kernel, dim3((E + 255) / 256), dim3(256), 0, st, h->done, E, net->ro_mask + (size_t)t * E);
     }
-    rc = solow ? launch_forward(net, E, obs, h->so.history, net->mu, net->sigma, net->ro_boot, false)
-               : launch_forward(net, E, obs, nullptr, net->mu, net->sigma, net->ro_boot, false, h->tr.nhist);
-    if (rc) return rc;
-    // rewards clipped to [-2, 2] (paac.py:145), masked n-step return (paac.py:167-172), adv / scale (paac.py:177)
-    if ((rc = launch_returns(h, net->ro_rew, net->ro_val, net->ro_mask, net->ro_boot, T, E, net->cfg.gamma, 1.0f, net->cfg.scale, -2.f, 2.f,
-                             net->ro_y, net->ro_adv)))
-        return ffail(net, rc, h->err);
     FNET_HIP(net, hipGetLastError());
     h->step_in_flight = true;
     return GRL_OK;
