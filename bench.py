@@ -48,6 +48,8 @@ def parse():
                     help="conv: the full PAAC update (default); random: env-only rollout")
     ap.add_argument("--no-train", action="store_true", help="conv policy rollout without the gradient step")
     ap.add_argument("--fast-math", action="store_true", help="GRL_F_SWARM_FAST_MATH (not the parity default)")
+    ap.add_argument("--single-stream", action="store_true",
+                    help="GRL_NET_F_SINGLE_STREAM: every chunk on one stream (for rocprofv3 passes: clean per-kernel durations)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the rollout_only / env_only side measurements")
     ap.add_argument("--cpu-sample-envs", type=int, default=2048)
@@ -190,7 +192,7 @@ def main():
     net = None
     if args.policy == "conv":
         from goldsrl import rollout as R
-        roll = R.ConvPolicyRollout(eng, T, train=not args.no_train)
+        roll = R.ConvPolicyRollout(eng, T, train=not args.no_train, reserved=4 if args.single_stream else 0)
         net = roll.net
         if world > 1:
             uid = net.comm_unique_id() if rank == 0 else np.zeros(net.comm_unique_id().size, np.uint8)
@@ -209,16 +211,20 @@ def main():
     for _ in range(args.warmup):
         roll.run()
     barrier()
-    eng.profile_enable(True)
-    if net is not None:
-        net.profile_enable(True)
+    eng.profile_enable(True)       # HIP events around the env step kernel only (it runs alone on the handle's stream)
     elapsed = timed(roll.run, eng.wait, args.steps)
     if dist is not None:
         dist.barrier()
     env_launches, env_kernel_ms = eng.profile_read()
     eng.profile_enable(False)
-    gemm = net.profile_read() if net is not None else None
+    # GEMM roofline: one more update of the same workload with a HIP event pair around every gemm_rowk / gemm_tn launch.
+    # Per-launch events need the launches serialised, so this pass runs on one stream; the timed region above alternates
+    # independent chunks between two streams, where kernels of different chunks overlap and have no clean duration.
+    gemm, gemm_step_s = None, None
     if net is not None:
+        net.profile_enable(True)
+        gemm_step_s = timed(roll.run, eng.wait, 1)
+        gemm = net.profile_read()
         net.profile_enable(False)
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64)
@@ -269,7 +275,8 @@ def main():
             "config": {"workload": "Swarm-v0 84x84, %d envs per GPU, T=%d PAAC update, conv policy of train_paac_conv.py "
                                    "(BASELINE configs[2])" % (E, T),
                        "envs_per_gpu": E, "rollout_steps": T, "policy": args.policy, "train": args.policy == "conv" and not args.no_train,
-                       "swarm_math": "fast" if args.fast_math else "exact", "env_state_dtype": "f64", "stages": stages},
+                       "swarm_math": "fast" if args.fast_math else "exact", "env_state_dtype": "f64", "stages": stages,
+                       "streams": 1 if (args.single_stream or args.policy != "conv") else 2},
         }
         if gemm is not None:
             launches, ms, flops = gemm
@@ -282,7 +289,10 @@ def main():
             out["roofline"] = {"bound": "mfma", "kernel": "gemm_rowk / gemm_tn (fp32 v_mfma_f32_32x32x2_f32 implicit GEMMs)",
                                "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TFLOPS,
                                "traffic": gtraffic, "launches": launches, "gemm_ms_total": ms,
-                               "gemm_share_of_step": (ms * 1e-3) / elapsed if world == 1 else None,
+                               "gemm_share_of_step": (ms * 1e-3) / gemm_step_s if gemm_step_s else None,
+                               "measured": "HIP event pair around every GEMM launch of ONE extra update run right after the timed "
+                                           "region on a single stream (%.1f ms); the timed region itself alternates chunks between "
+                                           "two streams (GRL_NET_F_SINGLE_STREAM off)" % (gemm_step_s * 1e3 if gemm_step_s else 0.0),
                                "flops_per_launch_avg": flops / max(launches, 1)}
             out["roofline_env_step"] = env_roof
         else:

@@ -43,45 +43,60 @@ using GatherT2 = ConvGather<10, 10, 1, 1, -1, -1, 2, 2, 64, 9, 9, true>;      //
 
 }  // namespace grl
 
-struct grl_net {
-    grl_handle *h;
-    grl_net_config cfg;
-    std::string err;
-    int chunk;                 // samples per pass
-    float *params, *grads, *adam_m, *adam_v;
-    float *paramsT;            // W^T of every GEMM layer at the same flat offsets ([N][K]: the forward's Bt operand)
-    long adam_t;
+// Per-stream workspace: every buffer one chunk's forward / backward pass writes.  Independent chunks are enqueued
+// alternately on two "lanes" (two HIP streams, two copies of this struct) so that the memory-bound helper kernels of one
+// chunk overlap the MFMA GEMMs of the other; grl_net derives from it, so kernels keep using net->d1 etc. and
+// use_lane() swaps the whole pointer set between chunk enqueues (host-side, sequential).
+struct NetLane {
+    float *grads;              // this lane's gradient accumulator (lane 0's is THE gradient; lane 1's is added before the all-reduce)
     // forward activations (chunk)
     float *a1, *a2, *a3, *d1, *d2, *p1, *v1, *v2;
     // gradients of activations (chunk)
     float *ga1, *ga2, *ga3, *gd1, *gd2, *gp1, *gv1, *gv2;
-    float *w3t, *w2t;          // rearranged conv weights for the data gradients
     // shared-trunk evaluation of conv1/conv2 (net_shared.inc): per-ENV tensors
-    int shared_trunk;
     float *sraw, *a1sh, *z2sh, *dz2, *gt;
     // shared conv3 gradients: per-env a2sh = relu(z2sh), DZ3; per (agent, slot <= 9 touched conv2 pixels): pixel id,
     // a2_a[u], a2_a[u] - a2sh[u], T3(dz3_a)[u], masked dz2_a[u]; tmpw3: correction GEMM output before the tap flip
     float *a2sh, *d2s, *v2s, *gsl, *dza, *dz3sh, *tmpw3;
     float *at2, *dl2, *tt2, *tmpw2;   // conv2-level corrections as class-major GEMM operands (net_shared.inc)
-    int npad;
-    // shared conv3 forward: z3sh = conv3(a2sh) + b3 per env, w3f[(tap,co)][ci] = W3[tap][ci][co]; the per-slot products
-    // (a2_a - a2sh)[u] . W3[tap] (n*9 x 576) live in the a2 buffer, which has no other use in shared-trunk mode
-    float *z3sh, *w3f;
+    // shared conv3 forward: z3sh = conv3(a2sh) + b3 per env; the per-slot products (a2_a - a2sh)[u] . W3[tap]
+    // (n*9 x 576) live in the a2 buffer, which has no other use in shared-trunk mode
+    float *z3sh;
     // dense1 on the shared a3 (net_patch.inc): per-env a3sh and ysh = W^T a3sh + b; per agent the 5x5 patch values v3 and
     // differences d3 (1600 floats); group-sorted sample order for the patch GEMMs
     float *a3sh, *d3, *v3, *ysh;
     float *gd1sh, *gsh3, *g3p, *dz3p;     // gradient side: per-env sum of gd1, its dense1 data gradient, per-agent patch gradients
-    int *perm, *goffp, *blkcnt, *blkoff, *sbeg, *send, *sgrp, ptiles, pslices;
+    int *perm, *goffp, *blkcnt, *blkoff, *sbeg, *send, *sgrp;
     signed char *tilegroup, *org;
     signed char *ulist;
     float *slab;               // split-M partial sums
-    size_t slab_floats;
+    float *slab1h;             // one-hot conv1 tap partials of agent_ds_kernel
     double *slab64;
+    float *ro_mu;              // chunk-sized scratch of the gradient step (cmu csigma cvs dzh cact cadv cy)
+    float *ws_a3, *ws_d1, *ws_d2, *ws_p1, *ws_v1, *ws_v2, *ws_a3sh, *ws_d3, *ws_v3;   // chunk workspace (the default binding)
+    float *ws_sraw, *ws_a2sh, *ws_d2s, *ws_v2s;
+    signed char *ws_ulist;
+    bool train_ready;
+};
+
+struct grl_net : NetLane {
+    grl_handle *h;
+    grl_net_config cfg;
+    std::string err;
+    int chunk;                 // samples per pass
+    float *params, *adam_m, *adam_v;
+    float *paramsT;            // W^T of every GEMM layer at the same flat offsets ([N][K]: the forward's Bt operand)
+    long adam_t;
+    float *w3t, *w2t;          // rearranged conv weights for the data gradients
+    float *w3f;                // w3f[(tap,co)][ci] = W3[tap][ci][co] (slot product GEMM of conv3's forward)
+    int shared_trunk;
+    int npad, ptiles, pslices;
+    size_t slab_floats;
     float *stats;              // device: loss sums
     // rollout storage (allocated by grl_net_rollout)
     int T, B;
     uint8_t *ro_lb, *ro_ab, *ro_pos;
-    float *ro_act, *ro_envact, *ro_val, *ro_rew, *ro_y, *ro_adv, *ro_boot, *ro_mu, *ro_sigma;
+    float *ro_act, *ro_envact, *ro_val, *ro_rew, *ro_y, *ro_adv, *ro_boot, *ro_sigma;
     float *mu, *sigma, *vs;    // (B,2) (B,2) (B) of the last predict
     uint8_t *tmp_lb, *tmp_ab, *tmp_pos;
     int tmp_envs;
@@ -94,18 +109,19 @@ struct grl_net {
     int last_n;                // samples in the last chunk (for read_activation)
     void *comm;                // ncclComm_t (RCCL) for the per-rollout gradient all-reduce, or nullptr
     int comm_world, comm_rank;
-    // Rollout-resident activations: the rollout's forward pass writes a3..v2 of every (step, chunk) into one
-    // T*B-sample buffer (20.7 KB per agent-sample, 136 GB at 32 768 envs x 20 steps -- what 288 GB of HBM is for) and
-    // the gradient step reads them back instead of recomputing conv3 and the dense stack.  Exact: parameters do
-    // not change between the two (paac.py:302-387).  keep_version tracks that; GRL_NET_F_RECOMPUTE_FORWARD or too
-    // little free memory selects recomputation.
-    float *ws_a3, *ws_d1, *ws_d2, *ws_p1, *ws_v1, *ws_v2, *ws_a3sh, *ws_d3, *ws_v3;   // chunk workspace (the default binding)
-    float *ws_sraw, *ws_a2sh, *ws_d2s, *ws_v2s;
-    signed char *ws_ulist;
+    // Rollout-resident activations: the rollout's forward pass writes its activations of every (step, chunk) into one
+    // T*B-sample buffer (what 288 GB of HBM is for) and the gradient step reads them back instead of recomputing the
+    // forward pass.  Exact: parameters do not change between the two (paac.py:302-387).  keep_version tracks that;
+    // GRL_NET_F_RECOMPUTE_FORWARD or too little free memory selects recomputation.
     int keep_level;            // 0: nothing resident, 1: conv3/dense activations, 2: + the per-env trunk tensors the gradient step reads
     float *keep;
     size_t keep_slots;
     long param_version, keep_version;
+    // lanes
+    NetLane lanes[2];
+    hipStream_t lane_stream[2];      // [0] = the handle's stream
+    hipEvent_t ev_fork, ev_join;
+    int cur_lane, last_lane;
 };
 
 namespace grl {
@@ -125,6 +141,32 @@ static int nalloc(grl_net *n, T **p, size_t count) {
     NET_HIP(n, hipMalloc((void **)p, count * sizeof(T)));
     n->allocs.push_back(*p);
     NET_HIP(n, hipMemsetAsync(*p, 0, count * sizeof(T), n->h->stream));
+    return GRL_OK;
+}
+
+// ---- lanes: swap the per-stream workspace (and the stream kernels are enqueued on) between chunk enqueues
+static void use_lane(grl_net *net, int k) {
+    if (k == net->cur_lane) return;
+    net->lanes[net->cur_lane] = static_cast<NetLane &>(*net);
+    static_cast<NetLane &>(*net) = net->lanes[k];
+    net->h->stream = net->lane_stream[k];
+    net->cur_lane = k;
+}
+static int lanes_active(const grl_net *net) { return (net->lane_stream[1] && !net->prof_on) ? 2 : 1; }
+// lane 1 sees everything enqueued on the main stream so far
+static int lanes_fork(grl_net *net) {
+    if (lanes_active(net) < 2) return GRL_OK;
+    use_lane(net, 0);
+    NET_HIP(net, hipEventRecord(net->ev_fork, net->lane_stream[0]));
+    NET_HIP(net, hipStreamWaitEvent(net->lane_stream[1], net->ev_fork, 0));
+    return GRL_OK;
+}
+// the main stream sees everything enqueued on lane 1; lane 0 becomes current again
+static int lanes_join(grl_net *net) {
+    use_lane(net, 0);
+    if (lanes_active(net) < 2) return GRL_OK;
+    NET_HIP(net, hipEventRecord(net->ev_join, net->lane_stream[1]));
+    NET_HIP(net, hipStreamWaitEvent(net->lane_stream[0], net->ev_join, 0));
     return GRL_OK;
 }
 
@@ -393,14 +435,46 @@ static int forward_chunk(grl_net *net, const uint8_t *lb, const uint8_t *ab, con
 static int forward_all(grl_net *net, const uint8_t *lb, const uint8_t *ab, const uint8_t *pos, int n_envs, float *mu, float *sigma,
                        float *vs, long slot0 = -1) {
     const int ce = net->chunk / 10;
+    int rc = lanes_fork(net);
+    if (rc) return rc;
+    const int nl = lanes_active(net);
     for (int e0 = 0; e0 < n_envs; e0 += ce) {
         int ne = n_envs - e0 < ce ? n_envs - e0 : ce;
+        use_lane(net, (e0 / ce) % nl);      // independent chunks alternate between the two streams
+        net->last_lane = net->cur_lane;
         bind_activations(net, slot0 < 0 ? -1 : slot0 + e0 / ce);
-        int rc = forward_chunk(net, lb + (size_t)e0 * 160, ab + (size_t)e0 * 20, pos + (size_t)e0 * 20, ne, mu + (size_t)e0 * 20,
-                               sigma + (size_t)e0 * 20, vs + (size_t)e0 * 10);
-        if (rc) return rc;
+        rc = forward_chunk(net, lb + (size_t)e0 * 160, ab + (size_t)e0 * 20, pos + (size_t)e0 * 20, ne, mu + (size_t)e0 * 20,
+                           sigma + (size_t)e0 * 20, vs + (size_t)e0 * 10);
+        if (rc) { (void)lanes_join(net); return rc; }
     }
-    return GRL_OK;
+    return lanes_join(net);
+}
+
+// forward-pass workspace of the lane currently loaded into *net
+static int alloc_lane_forward(grl_net *n) {
+    const size_t c = n->chunk;
+    int rc = GRL_OK;
+    auto A = [&](float **p, size_t cnt) { if (rc == GRL_OK) rc = nalloc(n, p, cnt); };
+    A(&n->grads, ConvOffsets::total);
+    A(&n->a2, c * 5184); A(&n->d1, c * 512); A(&n->d2, c * 256); A(&n->p1, c * 512); A(&n->v1, c * 512); A(&n->v2, c * 256);
+    if (!n->shared_trunk) { A(&n->a1, c * 12800); A(&n->a3, c * 3136); }       // per-agent tensors the shared evaluation never forms
+    A(&n->sraw, (c / 10) * 12800); A(&n->a1sh, (c / 10) * 12800); A(&n->z2sh, (c / 10) * 5184);
+    A(&n->a2sh, (c / 10) * 5184); A(&n->d2s, c * 9 * 64); A(&n->v2s, c * 9 * 64); A(&n->z3sh, (c / 10) * 3136);
+    if (rc == GRL_OK) rc = nalloc(n, &n->ulist, c * 9);
+    A(&n->a3sh, (c / 10) * 3136); A(&n->d3, c * 1600); A(&n->v3, c * 1600); A(&n->ysh, (c / 10) * 512);
+    n->ws_a3 = n->a3; n->ws_d1 = n->d1; n->ws_d2 = n->d2; n->ws_p1 = n->p1; n->ws_v1 = n->v1; n->ws_v2 = n->v2;
+    n->ws_a3sh = n->a3sh; n->ws_d3 = n->d3; n->ws_v3 = n->v3;
+    n->ws_sraw = n->sraw; n->ws_a2sh = n->a2sh; n->ws_d2s = n->d2s; n->ws_v2s = n->v2s; n->ws_ulist = n->ulist;
+    if (rc == GRL_OK) rc = nalloc(n, &n->perm, (size_t)n->ptiles * 256);
+    if (rc == GRL_OK) rc = nalloc(n, &n->goffp, 16);
+    if (rc == GRL_OK) rc = nalloc(n, &n->sbeg, n->pslices);
+    if (rc == GRL_OK) rc = nalloc(n, &n->send, n->pslices);
+    if (rc == GRL_OK) rc = nalloc(n, &n->sgrp, n->pslices);
+    if (rc == GRL_OK) rc = nalloc(n, &n->blkcnt, ((c + 255) / 256) * 9);
+    if (rc == GRL_OK) rc = nalloc(n, &n->blkoff, ((c + 255) / 256) * 9);
+    if (rc == GRL_OK) rc = nalloc(n, &n->tilegroup, (size_t)n->ptiles);
+    if (rc == GRL_OK) rc = nalloc(n, &n->org, c);
+    return rc;
 }
 
 static int ensure_tmp_obs(grl_net *net, int n_envs) {
@@ -450,35 +524,34 @@ int grl_net_create(grl_handle *h, const grl_net_config *cfg, grl_net **out) {
     grl_net *n = new grl_net();
     n->h = h; n->cfg = *cfg; n->chunk = cfg->max_chunk_samples; n->adam_t = 0;
     n->T = 0; n->B = 0; n->tmp_envs = 0; n->act_counter = 0; n->prof_on = false; n->prof_used = 0; n->prof_flops = 0; n->last_n = 0;
-    n->ro_lb = nullptr; n->slab = nullptr; n->slab_floats = 0; n->slab64 = nullptr; n->w3t = n->w2t = nullptr;
-    n->ga1 = nullptr; n->mu = n->sigma = n->vs = nullptr;
+    n->ro_lb = nullptr; n->slab_floats = 0; n->w3t = n->w2t = nullptr;
+    n->mu = n->sigma = n->vs = nullptr;
     n->keep_level = 0;
     n->keep = nullptr; n->keep_slots = 0; n->param_version = 0; n->keep_version = -1;
-    size_t c = n->chunk;
+    n->shared_trunk = (cfg->reserved & GRL_NET_F_PER_AGENT_TRUNK) ? 0 : 1;     // the plain per-agent evaluation is the A/B reference
+    n->cur_lane = 0; n->last_lane = 0;
+    n->lane_stream[0] = h->stream; n->lane_stream[1] = nullptr; n->ev_fork = n->ev_join = nullptr;
+    const size_t c = n->chunk;
+    n->ptiles = (int)((c + 255) / 256) + 9;
+    n->pslices = (int)((c + 1023) / 1024) + 9;
+    n->npad = (int)((c + 255) / 256 * 256);
     int rc = GRL_OK;
     auto A = [&](float **p, size_t cnt) { if (rc == GRL_OK) rc = nalloc(n, p, cnt); };
-    A(&n->params, ConvOffsets::total); A(&n->paramsT, ConvOffsets::total); A(&n->grads, ConvOffsets::total); A(&n->adam_m, ConvOffsets::total); A(&n->adam_v, ConvOffsets::total);
-    A(&n->a1, c * 12800); A(&n->a2, c * 5184); A(&n->a3, c * 3136); A(&n->d1, c * 512); A(&n->d2, c * 256);
-    A(&n->p1, c * 512); A(&n->v1, c * 512); A(&n->v2, c * 256); A(&n->stats, 16);
-    n->ws_a3 = n->a3; n->ws_d1 = n->d1; n->ws_d2 = n->d2; n->ws_p1 = n->p1; n->ws_v1 = n->v1; n->ws_v2 = n->v2;
-    n->shared_trunk = (cfg->reserved & 1) ? 0 : 1;     // GRL_NET_F_PER_AGENT_TRUNK: the plain per-agent evaluation (A/B reference)
-    A(&n->sraw, (c / 10) * 12800); A(&n->a1sh, (c / 10) * 12800); A(&n->z2sh, (c / 10) * 5184);
-    A(&n->a2sh, (c / 10) * 5184); A(&n->d2s, c * 9 * 64); A(&n->v2s, c * 9 * 64); A(&n->z3sh, (c / 10) * 3136); A(&n->w3f, 576 * 64);
-    if (rc == GRL_OK) rc = nalloc(n, &n->ulist, c * 9);
-    n->ptiles = (int)((c + 255) / 256) + 9;
-    A(&n->a3sh, (c / 10) * 3136); A(&n->d3, c * 1600); A(&n->v3, c * 1600); A(&n->ysh, (c / 10) * 512);
-    n->ws_a3sh = n->a3sh; n->ws_d3 = n->d3; n->ws_v3 = n->v3;
-    n->ws_sraw = n->sraw; n->ws_a2sh = n->a2sh; n->ws_d2s = n->d2s; n->ws_v2s = n->v2s; n->ws_ulist = n->ulist;
-    if (rc == GRL_OK) rc = nalloc(n, &n->perm, (size_t)n->ptiles * 256);
-    if (rc == GRL_OK) rc = nalloc(n, &n->goffp, 16);
-    n->pslices = (int)((c + 1023) / 1024) + 9;
-    if (rc == GRL_OK) rc = nalloc(n, &n->sbeg, n->pslices);
-    if (rc == GRL_OK) rc = nalloc(n, &n->send, n->pslices);
-    if (rc == GRL_OK) rc = nalloc(n, &n->sgrp, n->pslices);
-    if (rc == GRL_OK) rc = nalloc(n, &n->blkcnt, ((c + 255) / 256) * 9);
-    if (rc == GRL_OK) rc = nalloc(n, &n->blkoff, ((c + 255) / 256) * 9);
-    if (rc == GRL_OK) rc = nalloc(n, &n->tilegroup, (size_t)n->ptiles);
-    if (rc == GRL_OK) rc = nalloc(n, &n->org, c);
+    A(&n->params, ConvOffsets::total); A(&n->paramsT, ConvOffsets::total); A(&n->adam_m, ConvOffsets::total); A(&n->adam_v, ConvOffsets::total);
+    A(&n->w3f, 576 * 64); A(&n->stats, 16);
+    const int nlanes = (cfg->reserved & GRL_NET_F_SINGLE_STREAM) ? 1 : 2;
+    for (int k = 0; k < nlanes && rc == GRL_OK; ++k) {       // lane k's forward workspace (allocated into *n, then parked)
+        static_cast<NetLane &>(*n) = NetLane{};
+        rc = alloc_lane_forward(n);
+        n->lanes[k] = static_cast<NetLane &>(*n);
+    }
+    static_cast<NetLane &>(*n) = n->lanes[0];
+    if (rc == GRL_OK && nlanes == 2) {
+        if (hipStreamCreateWithFlags(&n->lane_stream[1], hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&n->ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&n->ev_join, hipEventDisableTiming) != hipSuccess)
+            rc = nfail(n, GRL_E_HIP, "creating the second lane's stream/events failed");
+    }
     if (rc == GRL_OK && hipFuncSetAttribute((const void *)expand_conv2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int)EXP2_LDS_BYTES) != hipSuccess)
         rc = nfail(n, GRL_E_HIP, "hipFuncSetAttribute(expand_conv2_kernel)");
@@ -501,6 +574,10 @@ int grl_net_destroy(grl_net *n) {
         ncclCommDestroy((ncclComm_t)n->comm);
         (void)hipGetLastError();   // RCCL teardown may leave a stale HIP error on this thread
     }
+    use_lane(n, 0);
+    if (n->lane_stream[1]) { hipStreamSynchronize(n->lane_stream[1]); hipStreamDestroy(n->lane_stream[1]); }
+    if (n->ev_fork) hipEventDestroy(n->ev_fork);
+    if (n->ev_join) hipEventDestroy(n->ev_join);
     for (void *p : n->allocs) hipFree(p);
     if (n->keep) hipFree(n->keep);
     for (hipEvent_t ev : n->prof_ev) hipEventDestroy(ev);
@@ -565,9 +642,16 @@ int grl_net_predict_obs(grl_net *n, int32_t n_envs, const uint8_t *lb, const uin
     return download_heads(n, n_envs * 10, mu_host, sigma_host, vs_host);
 }
 
+static int read_activation_impl(grl_net *n, const char *which, float *host, size_t bytes);
 int grl_net_read_activation(grl_net *n, const char *which, float *host, size_t bytes) {
     if (!n || !which || !host) return GRL_E_INVALID;
     hipSetDevice(n->h->cfg.device_id);
+    use_lane(n, n->last_lane);      // the last chunk's tensors live in the lane that ran it
+    int rc = read_activation_impl(n, which, host, bytes);
+    use_lane(n, 0);
+    return rc;
+}
+static int read_activation_impl(grl_net *n, const char *which, float *host, size_t bytes) {
     std::string w(which);
     const float *src = nullptr;
     size_t per = 0;

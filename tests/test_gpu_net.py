@@ -188,22 +188,23 @@ def test_gradient_paths_agree_at_tile_multiple_sizes():
     flat = flat + (rng.normal(size=flat.size) * 0.01).astype(np.float32)
     act, adv, y = _train_inputs(E, seed=5)
     grads, stats = [], []
-    for chunk, flags in ((2560, 0), (1280, 0), (1280, 1), (640, 1)):
+    # flags: 1 = per-agent evaluation, 4 = single stream (the default alternates chunks between two streams/lanes)
+    for chunk, flags in ((2560, 0), (1280, 0), (640, 4), (1280, 1), (640, 1)):
         net = _ffi_net.ConvNet(eng, max_chunk_samples=chunk, reserved=flags)
         net.set_params(flat)
         stats.append(net.train_obs(*obs, act, adv, y, lr=0.0, apply_update=False))
         grads.append(net.get_grads().astype(np.float64))
         net.close()
     shapes = NN.CONV_PARAM_SHAPES
-    ref = NN.unflatten_params(grads[3], shapes)
-    for g in grads[:3]:
+    ref = NN.unflatten_params(grads[4], shapes)
+    for g in grads[:4]:
         got = NN.unflatten_params(g, shapes)
         for name, _ in shapes:
             err = np.abs(got[name] - ref[name]).max() / (np.abs(ref[name]).max() + 1e-12)
             assert err < 5e-5, (name, err)
-    for s in stats[:3]:
-        np.testing.assert_allclose(s["loss"], stats[3]["loss"], rtol=1e-5)
-        np.testing.assert_allclose(s["global_norm"], stats[3]["global_norm"], rtol=1e-5)
+    for s in stats[:4]:
+        np.testing.assert_allclose(s["loss"], stats[4]["loss"], rtol=1e-5)
+        np.testing.assert_allclose(s["global_norm"], stats[4]["global_norm"], rtol=1e-5)
 
 
 def test_rccl_communicator_world_size_1():

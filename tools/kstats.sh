@@ -2,7 +2,7 @@
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf gpurun_out/ks && mkdir -p gpurun_out
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ks -- python3 bench.py --envs 4096 --steps 2 --warmup 1 --no-cpu-baseline --no-extras > gpurun_out/ks.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ks -- python3 bench.py --envs 4096 --steps 2 --warmup 1 --no-cpu-baseline --no-extras --single-stream > gpurun_out/ks.log 2>&1
 python3 - <<'PY'
 import csv, glob
 f = glob.glob("gpurun_out/ks/*/*_kernel_stats.csv")[0]

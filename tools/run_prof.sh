@@ -4,7 +4,7 @@ set -e
 TAG=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
-ARGS="bench.py --no-cpu-baseline --no-extras $@"
+ARGS="bench.py --no-cpu-baseline --no-extras --single-stream $@"
 echo "stats pass" >> gpurun_out/prof_${TAG}.progress
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG}_stats -- python3 $ARGS > gpurun_out/prof_${TAG}_stats.log 2>&1
 echo "fetch pass" >> gpurun_out/prof_${TAG}.progress
