@@ -219,7 +219,7 @@ def main():
     eng.profile_enable(False)
     # GEMM roofline: one more update of the same workload with a HIP event pair around every gemm_rowk / gemm_tn launch.
     # Per-launch events need the launches serialised, so this pass runs on one stream; the timed region above alternates
-    # independent chunks between two streams, where kernels of different chunks overlap and have no clean duration.
+    # independent chunks between four streams, where kernels of different chunks overlap and have no clean duration.
     gemm, gemm_step_s = None, None
     if net is not None:
         net.profile_enable(True)
@@ -276,7 +276,7 @@ def main():
                                    "(BASELINE configs[2])" % (E, T),
                        "envs_per_gpu": E, "rollout_steps": T, "policy": args.policy, "train": args.policy == "conv" and not args.no_train,
                        "swarm_math": "fast" if args.fast_math else "exact", "env_state_dtype": "f64", "stages": stages,
-                       "streams": 1 if (args.single_stream or args.policy != "conv") else 2},
+                       "streams": 1 if (args.single_stream or args.policy != "conv") else 4},
         }
         if gemm is not None:
             launches, ms, flops = gemm
@@ -291,8 +291,8 @@ def main():
                                "traffic": gtraffic, "launches": launches, "gemm_ms_total": ms,
                                "gemm_share_of_step": (ms * 1e-3) / gemm_step_s if gemm_step_s else None,
                                "measured": "HIP event pair around every GEMM launch of ONE extra update run right after the timed "
-                                           "region on a single stream (%.1f ms); the timed region itself alternates chunks between "
-                                           "two streams (GRL_NET_F_SINGLE_STREAM off)" % (gemm_step_s * 1e3 if gemm_step_s else 0.0),
+                                           "region on a single stream (%.1f ms); the timed region itself deals chunks round-robin "
+                                           "to four streams (GRL_NET_F_SINGLE_STREAM off)" % (gemm_step_s * 1e3 if gemm_step_s else 0.0),
                                "flops_per_launch_avg": flops / max(launches, 1)}
             out["roofline_env_step"] = env_roof
         else:

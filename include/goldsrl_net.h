@@ -28,8 +28,9 @@ extern "C" {
 /* Recompute conv3 and the dense stack in the gradient step instead of keeping the rollout's activations resident
  * in HBM (22 KB per agent-sample and step; chosen automatically when that buffer does not fit).  Bit-identical. */
 #define GRL_NET_F_RECOMPUTE_FORWARD 0x2
-/* Enqueue every chunk on the handle's stream instead of alternating independent chunks between two streams (the
- * default: memory-bound helper kernels of one chunk overlap the MFMA GEMMs of the other).  Same results. */
+/* Enqueue every chunk on the handle's stream instead of dealing independent chunks round-robin to four streams (the
+ * default: memory-bound helper kernels of one chunk overlap the MFMA GEMMs of the others; GRL_NET_LANES=1..8 in the
+ * environment overrides the count).  Same results up to the order in which per-lane gradient sums are added. */
 #define GRL_NET_F_SINGLE_STREAM 0x4
 
 typedef struct grl_net_config {
