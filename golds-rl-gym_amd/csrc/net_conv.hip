@@ -621,6 +621,25 @@ static int get_flat(grl_net *n, const float *src, float *host, int64_t cnt) {
 int grl_net_get_params(grl_net *n, float *host, int64_t cnt) { return get_flat(n, n ? n->params : nullptr, host, cnt); }
 int grl_net_get_grads(grl_net *n, float *host, int64_t cnt) { return get_flat(n, n ? n->grads : nullptr, host, cnt); }
 
+int grl_net_get_optimizer_state(grl_net *n, float *m_host, float *v_host, int64_t cnt, int64_t *step_out) {
+    if (!n || !m_host || !v_host || !step_out) return GRL_E_INVALID;
+    int rc = get_flat(n, n->adam_m, m_host, cnt);
+    if (rc == GRL_OK) rc = get_flat(n, n->adam_v, v_host, cnt);
+    *step_out = n->adam_t;
+    return rc;
+}
+
+int grl_net_set_optimizer_state(grl_net *n, const float *m_host, const float *v_host, int64_t cnt, int64_t step) {
+    if (!n || !m_host || !v_host || step < 0) return GRL_E_INVALID;
+    if (cnt != ConvOffsets::total) return nfail(n, GRL_E_SIZE, "grl_net_set_optimizer_state: expected " + std::to_string((long)ConvOffsets::total) + " floats");
+    hipSetDevice(n->h->cfg.device_id);
+    NET_HIP(n, hipStreamSynchronize(n->h->stream));
+    NET_HIP(n, hipMemcpy(n->adam_m, m_host, cnt * 4, hipMemcpyHostToDevice));
+    NET_HIP(n, hipMemcpy(n->adam_v, v_host, cnt * 4, hipMemcpyHostToDevice));
+    n->adam_t = (long)step;
+    return GRL_OK;
+}
+
 static int download_heads(grl_net *n, int B, float *mu_host, float *sigma_host, float *vs_host) {
     NET_HIP(n, hipStreamSynchronize(n->h->stream));
     if (mu_host) NET_HIP(n, hipMemcpy(mu_host, n->mu, (size_t)B * 8, hipMemcpyDeviceToHost));

@@ -365,6 +365,22 @@ int grl_fnet_set_params(grl_fnet *n, const float *host, int64_t cnt) { return fc
 int grl_fnet_get_params(grl_fnet *n, float *host, int64_t cnt) { return fcopy_flat(n, n ? n->params : nullptr, host, cnt, false); }
 int grl_fnet_get_grads(grl_fnet *n, float *host, int64_t cnt) { return fcopy_flat(n, n ? n->grads : nullptr, host, cnt, false); }
 
+int grl_fnet_get_optimizer_state(grl_fnet *n, float *m_host, float *v_host, int64_t cnt, int64_t *step_out) {
+    if (!n || !m_host || !v_host || !step_out) return GRL_E_INVALID;
+    int rc = fcopy_flat(n, n->adam_m, m_host, cnt, false);
+    if (rc == GRL_OK) rc = fcopy_flat(n, n->adam_v, v_host, cnt, false);
+    *step_out = n->adam_t;
+    return rc;
+}
+
+int grl_fnet_set_optimizer_state(grl_fnet *n, const float *m_host, const float *v_host, int64_t cnt, int64_t step) {
+    if (!n || !m_host || !v_host || step < 0) return GRL_E_INVALID;
+    int rc = fcopy_flat(n, n->adam_m, (float *)m_host, cnt, true);
+    if (rc == GRL_OK) rc = fcopy_flat(n, n->adam_v, (float *)v_host, cnt, true);
+    if (rc == GRL_OK) n->adam_t = (long)step;
+    return rc;
+}
+
 static int fdownload(grl_fnet *net, int n, float *mu, float *sigma, float *vs) {
     const int A = net->cfg.num_actions;
     FNET_HIP(net, hipStreamSynchronize(net->h->stream));

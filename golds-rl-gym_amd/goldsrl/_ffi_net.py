@@ -22,6 +22,8 @@ NET_SIGNATURES = {
     "grl_net_set_params": (C.c_int, [_P, _P, C.c_int64]),
     "grl_net_get_params": (C.c_int, [_P, _P, C.c_int64]),
     "grl_net_get_grads": (C.c_int, [_P, _P, C.c_int64]),
+    "grl_net_get_optimizer_state": (C.c_int, [_P, _P, _P, C.c_int64, C.POINTER(C.c_int64)]),
+    "grl_net_set_optimizer_state": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64]),
     "grl_net_predict": (C.c_int, [_P, _P, _P, _P]),
     "grl_net_predict_obs": (C.c_int, [_P, _I, _P, _P, _P, _P, _P, _P]),
     "grl_net_rollout": (C.c_int, [_P, _I, _I]),
@@ -119,6 +121,29 @@ class ConvNet(object):
         a = np.empty(self.num_params, np.float32)
         self._check(self.lib.grl_net_get_grads(self.n, _ffi._ptr(a), a.size))
         return a
+
+    def get_optimizer_state(self):
+        """Adam moments and the number of updates applied: with the parameters, the estimator's whole training state."""
+        m, v = np.empty(self.num_params, np.float32), np.empty(self.num_params, np.float32)
+        step = C.c_int64(0)
+        self._check(self.lib.grl_net_get_optimizer_state(self.n, _ffi._ptr(m), _ffi._ptr(v), m.size, C.byref(step)))
+        return {"adam_m": m, "adam_v": v, "adam_step": int(step.value)}
+
+    def set_optimizer_state(self, adam_m, adam_v, adam_step):
+        m, v = np.ascontiguousarray(adam_m, np.float32), np.ascontiguousarray(adam_v, np.float32)
+        self._check(self.lib.grl_net_set_optimizer_state(self.n, _ffi._ptr(m), _ffi._ptr(v), m.size, int(adam_step)))
+
+    def save_checkpoint(self, path, **extra):
+        """Flat-weights checkpoint (.npz): parameters in tf.trainable_variables() order, Adam state, caller's scalars."""
+        st = self.get_optimizer_state()
+        np.savez(path, params=self.get_params(), adam_m=st["adam_m"], adam_v=st["adam_v"], adam_step=st["adam_step"],
+                 **{k: np.asarray(v) for k, v in extra.items()})
+
+    def load_checkpoint(self, path):
+        with np.load(path) as z:
+            self.set_params(z["params"])
+            self.set_optimizer_state(z["adam_m"], z["adam_v"], int(z["adam_step"]))
+            return {k: z[k] for k in z.files if k not in ("params", "adam_m", "adam_v", "adam_step")}
 
     def predict(self):
         B = self.eng.E * 10

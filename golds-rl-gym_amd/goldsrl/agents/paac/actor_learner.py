@@ -34,5 +34,14 @@ class ActorLearner(object):
             return self.initial_lr - (self.global_step * self.initial_lr / self.lr_annealing_steps)
         return 0.0
 
+    def save_checkpoint(self, path):
+        """Flat-weights checkpoint of the bound estimator + global_step (the reference's Saver path, actor_learner.py:70-89,
+        is dead code in its scripts)."""
+        self.network.net.save_checkpoint(path, global_step=self.global_step)
+
+    def load_checkpoint(self, path):
+        extra = self.network.net.load_checkpoint(path)
+        self.global_step = int(extra.get("global_step", self.global_step))
+
     def cleanup(self):
         pass

@@ -75,3 +75,9 @@ class FlatPolicyVNetwork(object):
     def predict(self, states, histories, session=None):
         out = self.net.predict(states, histories)
         return {'mu': out['mu'], 'sigma': out['sigma']}          # the reference's predict returns only these two (:253-264)
+
+    def get_flat_params(self):
+        return self.net.get_params()
+
+    def set_flat_params(self, flat):
+        self.net.set_params(flat)

@@ -46,6 +46,9 @@ int64_t grl_fnet_num_params(const grl_fnet *net);
 int grl_fnet_set_params(grl_fnet *net, const float *host, int64_t n);
 int grl_fnet_get_params(grl_fnet *net, float *host, int64_t n);
 int grl_fnet_get_grads(grl_fnet *net, float *host, int64_t n);
+/* Adam moments + update count (flat-weights checkpoint, as grl_net_get/set_optimizer_state) */
+int grl_fnet_get_optimizer_state(grl_fnet *net, float *m_host, float *v_host, int64_t n, int64_t *step_out);
+int grl_fnet_set_optimizer_state(grl_fnet *net, const float *m_host, const float *v_host, int64_t n, int64_t step);
 
 /* network.predict(states, histories) + the value head, on HOST arrays: states (n,S0), history (n,T,D),
  * outputs mu (n,A) sigma (n,A) vs (n,) (any may be NULL).  Synchronous. */

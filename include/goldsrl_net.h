@@ -54,6 +54,11 @@ int64_t grl_net_num_params(const grl_net *net);
 int grl_net_set_params(grl_net *net, const float *host, int64_t n);
 int grl_net_get_params(grl_net *net, float *host, int64_t n);
 int grl_net_get_grads(grl_net *net, float *host, int64_t n);   /* flat gradient of the last grl_net_train call (before clipping) */
+/* Adam moments (flat, parameter order) and the number of updates applied so far: with the parameters this is the whole
+ * training state of the estimator (flat-weights checkpoint; the reference's tf.train.Saver path, actor_learner.py:70-89,
+ * is disabled in its scripts). */
+int grl_net_get_optimizer_state(grl_net *net, float *m_host, float *v_host, int64_t n, int64_t *step_out);
+int grl_net_set_optimizer_state(grl_net *net, const float *m_host, const float *v_host, int64_t n, int64_t step);
 
 /* network.predict(states) (policy_v_network.py:69-80) on the CURRENT observation of the Swarm
  * handle: B = 10*num_envs agent-samples in env-major order.  Outputs are HOST arrays (may be NULL):

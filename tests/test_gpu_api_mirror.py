@@ -185,3 +185,76 @@ def test_flat_paac_learner_runs_updates():
     assert learner.rescale_reward(-5.0) == -2 and learner.rescale_reward(0.3) == 0.3      # actor_learner.py:91-97
     out = learner.network.predict(np.array([[0.65, 0.0]], np.float32), np.zeros((1, 5, 2), np.float32))
     assert set(out) == {"mu", "sigma"}
+
+
+def _conv_conf():
+    return dict(name='local_learning', num_actions=2, clip_norm=40.0, clip_norm_type='global', device='/gpu:0',
+                entropy_regularisation_strength=0.02, scale=1000.0, height=84, width=84, channels=3)
+
+
+def test_swarm_policy_monitor_eval_episode(tmp_path):
+    """one seeded eval episode on Swarm-eval-v0, swarm-eval.json written, replay reproduces the score."""
+    import json, queue
+    from goldsrl import envs, _ffi
+    from goldsrl.agents.paac import policy_monitor as PM
+    from goldsrl.agents.paac.policy_v_network import ConvSingleAgentPolicyNetwork
+    from goldsrl.agents.state_processors import SwarmStateProcessor
+    learner_eng = _ffi.Engine(_ffi.ENV_SWARM, 2, seed=5)
+    learner_eng.reset()
+    global_net = ConvSingleAgentPolicyNetwork(_conv_conf()).bind(learner_eng, seed=11)
+    env = envs.make("Swarm-eval-v0")
+    writer = PM.ScalarWriter(str(tmp_path / "eval"))
+    mon = PM.SwarmPolicyMonitor(env, global_net, SwarmStateProcessor(grid_size=84), writer, network_conf=_conv_conf())
+    mon.actions_path = str(tmp_path / "swarm-eval.json")
+    np.random.seed(0)
+    total, length, rewards = mon.eval_once()
+    assert length == 128 and len(rewards) == 128 and np.isfinite(total) and total < 0      # TimeLimit cap; rewards are -energy
+    assert np.array_equal(mon.policy_net.get_flat_params(), global_net.get_flat_params())  # copy_params_op
+    saved = json.load(open(mon.actions_path))
+    assert saved['score'] == total and np.asarray(saved['actions']).shape == (128, 10, 2)
+    # the eval env re-seeds on reset: replaying the saved actions reproduces the episode
+    q = queue.Queue()
+    for a in saved['actions']:
+        q.put(np.asarray(a, np.float32))
+    total2, length2, rewards2 = mon.eval_once(actions=q)
+    assert length2 == 128
+    np.testing.assert_allclose(rewards2, rewards, rtol=1e-12)
+    lines = [json.loads(l) for l in open(tmp_path / "eval" / "scalars.jsonl")]
+    assert {l["tag"] for l in lines} == {"eval/total_reward", "eval/episode_length"}
+
+
+def test_solow_policy_monitor_and_checkpoint(tmp_path):
+    """Solow eval episode through FlatPolicyVNetwork.predict, and the flat-weights checkpoint round trip (8(f) rank 2)."""
+    from goldsrl import _ffi, _ffi_flat
+    from goldsrl.envs.fed_env import SolowEnv
+    from goldsrl.agents.paac import policy_monitor as PM
+    from goldsrl.agents.paac.policy_v_network import FlatPolicyVNetwork
+    from goldsrl.agents.state_processors import SolowStateProcessor
+    conf = dict(name='local_learning', num_actions=1, clip_norm=40.0, clip_norm_type='global', device='/gpu:0', scale=100.0,
+                static_size=2, temporal_size=2, entropy_regularisation_strength=0.02, static_hidden_size=32, rnn_hidden_size=32)
+    eng = _ffi.Engine(_ffi.ENV_SOLOW, 64, seed=3, max_episode_steps=1024)
+    eng.reset()
+    global_net = FlatPolicyVNetwork(conf).bind(eng, max_samples=64 * 8)
+    env = SolowEnv(p=1, q=1, T=16, seed=1692, max_episode_steps=16)
+    mon = PM.SolowPolicyMonitor(env, global_net, SolowStateProcessor(), PM.ScalarWriter(str(tmp_path / "e")), network_conf=conf)
+    np.random.seed(1)
+    total, length, rewards = mon.eval_once()
+    assert length == 16 and np.isfinite(total)
+    # checkpoint: two updates, save, two more, restore, the same two again -> identical parameters
+    net = global_net.net
+    for _ in range(2):
+        net.rollout(8); net.train_rollout(1e-3)
+    eng.wait()
+    path = str(tmp_path / "ckpt.npz")
+    net.save_checkpoint(path, global_step=1234)
+    state = {n: eng.get_state(n) for n in ("SOLOW_K", "SOLOW_Z", "SOLOW_E")} if hasattr(eng, "get_state") else None
+    p_saved, o_saved = net.get_params(), net.get_optimizer_state()
+    assert o_saved["adam_step"] == 2 and np.abs(o_saved["adam_m"]).max() > 0
+    for _ in range(2):
+        net.rollout(8); net.train_rollout(1e-3)
+    assert not np.array_equal(net.get_params(), p_saved)
+    extra = net.load_checkpoint(path)
+    assert int(extra["global_step"]) == 1234
+    assert np.array_equal(net.get_params(), p_saved)
+    o2 = net.get_optimizer_state()
+    assert o2["adam_step"] == 2 and np.array_equal(o2["adam_m"], o_saved["adam_m"]) and np.array_equal(o2["adam_v"], o_saved["adam_v"])
