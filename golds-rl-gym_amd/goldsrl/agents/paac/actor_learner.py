@@ -15,6 +15,10 @@ class ActorLearner(object):
         self.debugging_folder = args.debugging_folder
         self.max_global_steps = args.max_global_steps
         self.gamma = args.gamma
+        self.eval_every = getattr(args, 'eval_every', 0.0)              # seconds between eval episodes (reference: 30 s, in a thread)
+        self.checkpoint_every = getattr(args, 'checkpoint_every', 0)    # updates between flat-weights checkpoints (0: never)
+        self.checkpoint_path = getattr(args, 'checkpoint_path', 'checkpoint.npz')
+        self.resume = getattr(args, 'resume', None)
         self.network_creator = network_creator
         self.environment_creator = environment_creator
         self.network = network_creator()

@@ -29,6 +29,8 @@ class PAACLearner(ActorLearner):
         self.network.bind(self.engine, rnn_length=self.rnn_length, gamma=self.gamma,
                           max_samples=self.emulator_counts * self.max_local_steps)
         net = self.network.net
+        if self.resume:
+            self.load_checkpoint(self.resume)
         counter, global_step_start, start_time = 0, self.global_step, time.time()
         stats = None
         while self.global_step < self.max_global_steps:
@@ -69,7 +71,21 @@ class GridPAACLearner(PAACLearner):
         self.engine.reset()
         self.network.bind(self.engine, gamma=self.gamma)
         net = self.network.net
+        if self.resume:
+            self.load_checkpoint(self.resume)
         layout = 1 if self.reward_layout == 'reference' else 0
+        # paac.py:229-236,277-282: SwarmPolicyMonitor on Swarm-eval-v0, evaluated every 30 s.  The reference runs it in a
+        # thread; handles here are single-threaded, so the episode (its own 1-env handle) is played between two updates.
+        pe, last_eval = None, time.time()
+        eval_every = float(getattr(self, "eval_every", 0.0) or 0.0)
+        if eval_every > 0:
+            from ...envs import make
+            from ..state_processors import SwarmStateProcessor
+            from .policy_monitor import ScalarWriter, SwarmPolicyMonitor
+            pe = SwarmPolicyMonitor(env=make("Swarm-eval-v0"), global_policy_net=self.network,
+                                    state_processor=SwarmStateProcessor(grid_size=self.network.height),
+                                    summary_writer=ScalarWriter(self.debugging_folder), saver=None, network_conf=self.network.conf,
+                                    learner=self)
         logging.debug("Starting training at Step {}".format(self.global_step))
         counter, global_step_start, start_time = 0, self.global_step, time.time()
         stats = None
@@ -79,6 +95,12 @@ class GridPAACLearner(PAACLearner):
             self.global_step += self.max_local_steps * self.emulator_counts      # global_step += 1 per env per step (paac.py:341)
             stats = net.train_rollout(self.get_lr())
             counter += 1
+            if pe is not None and time.time() - last_eval >= eval_every:
+                pe.eval_once(max_sequence_length=self.rnn_length)
+                last_eval = time.time()
+            ckpt_every = int(getattr(self, "checkpoint_every", 0) or 0)
+            if ckpt_every > 0 and counter % ckpt_every == 0:
+                self.save_checkpoint(getattr(self, "checkpoint_path", "checkpoint.npz"))
             if counter % max(1, int(5048 / self.emulator_counts)) == 0:
                 curr_time = time.time()
                 logging.info("Ran {} steps, at {} steps/s ({} steps/s avg), loss {}"

@@ -71,6 +71,11 @@ def get_arg_parser():
     p.add_argument('--temporal-hidden-size', default=32, type=int)
     p.add_argument('--reward-layout', default='broadcast', choices=['broadcast', 'reference'], dest="reward_layout",
                    help="'reference' reproduces paac.py:331-338's (T, E*10) indexing (quirk Q4)")
+    p.add_argument('--eval-every', default=30.0, type=float, dest="eval_every",
+                   help="seconds between eval episodes on Swarm-eval-v0 (paac.py:277-282); 0 disables the monitor")
+    p.add_argument('--checkpoint-every', default=0, type=int, dest="checkpoint_every", help="updates between flat-weights checkpoints")
+    p.add_argument('--checkpoint-path', default='checkpoint.npz', type=str, dest="checkpoint_path")
+    p.add_argument('--resume', default=None, type=str, help="flat-weights checkpoint to start from")
     return p
 
 

@@ -157,9 +157,11 @@ def test_grid_runners_drop_in_protocol_swarm():
     assert not overs.any()
 
 
-def test_grid_paac_learner_runs_updates():
+def test_grid_paac_learner_runs_updates(tmp_path):
     from goldsrl.scripts import train_paac_conv as S
-    args = S.get_arg_parser().parse_args(["-ec", "64", "--max_local_steps", "5", "--max_global_steps", "640"])
+    ckpt = str(tmp_path / "ck.npz")
+    args = S.get_arg_parser().parse_args(["-ec", "64", "--max_local_steps", "5", "--max_global_steps", "640", "--eval-every", "1e-9",
+                                          "--checkpoint-every", "1", "--checkpoint-path", ckpt, "-df", str(tmp_path / "logs")])
     nc, ec = S.get_network_and_environment_creator(args)
     from goldsrl.agents.paac.emulator_runner import SwarmRunner
     from goldsrl.agents.paac.paac import GridPAACLearner
@@ -169,6 +171,16 @@ def test_grid_paac_learner_runs_updates():
     assert learner.global_step == 640 and np.isfinite(stats["loss"])
     assert learner.get_lr() == 1e-4 - 640 * 1e-4 / 80000000
     assert learner.rescale_reward(-5.0) == -5.0
+    # the monitor played an eval episode after every update, and the last checkpoint resumes the run
+    import json
+    tags = [json.loads(l)["tag"] for l in open(tmp_path / "logs" / "scalars.jsonl")]
+    assert tags.count("eval/total_reward") == 2 and tags.count("eval/episode_length") == 2
+    args2 = S.get_arg_parser().parse_args(["-ec", "64", "--max_local_steps", "5", "--max_global_steps", "960", "--eval-every", "0",
+                                           "--resume", ckpt])
+    nc2, ec2 = S.get_network_and_environment_creator(args2)
+    learner2 = GridPAACLearner(nc2, ec2, args2, SwarmRunner, state_processor=None)
+    learner2.train()
+    assert learner2.global_step == 960 and learner2.network.net.get_optimizer_state()["adam_step"] == 3
 
 
 def test_flat_paac_learner_runs_updates():
