@@ -257,3 +257,51 @@ def test_resident_rollout_activations_equal_recomputation():
         if s0 is not None:
             np.testing.assert_allclose(list(s0.values()), list(s1.values()), rtol=1e-6)
     assert np.abs(out[0][0][0]).max() > 0
+
+
+def test_full_size_forward_is_invariant_to_batch_position():
+    """BASELINE size (32 768 envs = 327 680 agent-samples, 8 chunks on 4 streams): a sample's outputs do not depend on
+    which chunk, stream, group tile or row it lands in -- re-evaluating 300 randomly picked envs as their own small batch
+    (different order, one chunk) gives bit-identical mu / sigma / vs.  Plus sanity of the full batch."""
+    from goldsrl import _ffi, _ffi_net
+    E = 32768
+    eng = _ffi.Engine(_ffi.ENV_SWARM, E, seed=77)
+    eng.reset()
+    rng = np.random.RandomState(5)
+    eng.step(O.swarm_transform_actions(rng.normal(size=(E, 10, 2)).astype(np.float32)))
+    net = _ffi_net.ConvNet(eng)
+    flat = _ffi_net.glorot_uniform_flat(seed=9)
+    flat = flat + (rng.normal(size=flat.size) * 0.02).astype(np.float32)
+    net.set_params(flat)
+    full = net.predict()
+    assert all(np.isfinite(full[k]).all() for k in full)
+    assert (full["sigma"] > 0).all() and (full["sigma"] < 1).all() and (np.abs(full["mu"]) <= 1).all() and (full["vs"] <= 0).all()
+    lb, ab, pos = eng.read("locust_bins"), eng.read("agent_bins"), eng.read("positions")
+    pick = rng.choice(E, size=300, replace=False)
+    sub = net.predict_obs(lb[pick], ab[pick], pos[pick])
+    idx = (pick[:, None] * 10 + np.arange(10)[None]).reshape(-1)
+    for k in ("mu", "sigma", "vs"):
+        assert np.array_equal(sub[k], full[k][idx]), k
+    net.close()
+
+
+def test_full_size_gradient_resident_equals_recomputed_and_is_reproducible():
+    """BASELINE size, one 2-step rollout (16 chunks over 4 streams): the gradient computed from the rollout-resident
+    activations equals the one recomputed from the stored observations (lr = 0 leaves the parameters unchanged but
+    invalidates the resident copy), bit for bit outside conv1's kernel (fp64 atomics), and the loss terms agree."""
+    from goldsrl import _ffi, _ffi_net
+    E, T = 32768, 2
+    eng = _ffi.Engine(_ffi.ENV_SWARM, E, seed=78)
+    eng.reset()
+    net = _ffi_net.ConvNet(eng)
+    net.set_params(_ffi_net.glorot_uniform_flat(seed=9))
+    net.rollout(T, 0)
+    s1 = net.train_rollout(0.0)
+    g1 = net.get_grads()
+    s2 = net.train_rollout(0.0)      # same rollout, forward pass recomputed
+    g2 = net.get_grads()
+    assert np.isfinite(g1).all() and np.abs(g1).max() > 0
+    assert np.array_equal(g1[6144:], g2[6144:])
+    np.testing.assert_allclose(g1[:6144], g2[:6144], rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(list(s1.values()), list(s2.values()), rtol=1e-6)
+    net.close()
