@@ -312,7 +312,7 @@ int grl_fnet_create(grl_handle *h, const grl_fnet_config *cfg, grl_fnet **out) {
     n->h = h; n->cfg = *cfg;
     n->off = make_offsets(cfg->temporal_size, cfg->static_size, cfg->num_actions);
     n->wso = ws_offsets(cfg->rnn_length, cfg->num_actions);
-    n->slab_blocks = 256;
+    n->slab_blocks = 512;      // two workgroups per CU (LDS 75 KB each)
     size_t ms = cfg->max_samples;
     const int A = cfg->num_actions, S0 = cfg->static_size, D = cfg->temporal_size, T = cfg->rnn_length;
     int rc = GRL_OK;
