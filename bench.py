@@ -32,6 +32,8 @@ for p in (ROOT, os.path.join(ROOT, "golds-rl-gym_amd")):
         sys.path.insert(0, p)
 
 SWARM_BYTES_PER_ENV_STEP = 4613      # algorithmic HBM bytes of one Swarm env-step
+SWARM_VALU_INSTR_PER_PAIR = 112        # counted in the ISA of swarm_kernel<MODE_STEP, exact> (hipcc 7.2, -O3 -ffp-contract=off)
+VALU_LANE_INSTR_PEAK = 256 * 4 * 16 * 2.4e9
 SWARM_PAIRS_PER_ENV_STEP = 7200      # pair interactions (6400 locust-locust + 800 agent-locust)
 HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3         # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
@@ -261,7 +263,14 @@ def main():
         env_roof = {"bound": "hbm", "kernel": "swarm_kernel<MODE_STEP>", "achieved": env_achieved, "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": env_achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_kernel_ms": k_avg_ms,
                     "launches": env_launches, "pair_interactions_per_s": E * SWARM_PAIRS_PER_ENV_STEP / (k_avg_ms * 1e-3),
-                    "note": "fp64-VALU/transcendental bound (~90 flop/B), not HBM bound: see DESIGN.md"}
+                    "note": "fp64-VALU/transcendental bound (~90 flop/B), not HBM bound: see DESIGN.md",
+                    # the bound that applies: the pair loop is 112 VALU instructions per pair in the gfx950 ISA (67 full-rate
+                    # fp64 fma/mul/add, 3 divisions = 6 div_scale + 3 rcp + 3 div_fmas + 3 div_fixup, 2 exp, 1 rsq, selects);
+                    # peak = 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz full-rate issue (rcp/rsq are quarter rate, so 100 % is not reachable)
+                    "valu_f64_issue": {"instr_per_pair": SWARM_VALU_INSTR_PER_PAIR,
+                                       "achieved": E * SWARM_PAIRS_PER_ENV_STEP * SWARM_VALU_INSTR_PER_PAIR / (k_avg_ms * 1e-3),
+                                       "peak": VALU_LANE_INSTR_PEAK, "unit": "lane-instructions/s",
+                                       "frac": E * SWARM_PAIRS_PER_ENV_STEP * SWARM_VALU_INSTR_PER_PAIR / (k_avg_ms * 1e-3) / VALU_LANE_INSTR_PEAK}}
         stages = "action draw + norm clip + SwarmEnv.step + TimeLimit + auto-reset + process_state + n-step returns"
         if args.policy == "conv":
             stages = ("conv policy forward (fp32) + Gaussian sample + norm clip + SwarmEnv.step + TimeLimit + auto-reset + "
