@@ -305,3 +305,60 @@ def test_full_size_gradient_resident_equals_recomputed_and_is_reproducible():
     np.testing.assert_allclose(g1[:6144], g2[:6144], rtol=1e-5, atol=1e-9)
     np.testing.assert_allclose(list(s1.values()), list(s2.values()), rtol=1e-6)
     net.close()
+
+
+def test_border_and_corner_agents_forward_and_gradients_match_oracle():
+    """Hand-made observations that put agents on the corners, edges and last rows/columns of the 84x84 grid, several agents
+    on ONE pixel, locusts piled on single bins and points outside the box (bin 255): the one-hot's conv1 cover is then
+    1x1 / 1x2 / 2x1 instead of 2x2, the touched conv2 block and the 5x5 conv3 patch are clipped by the map, and per-agent
+    corrections collide.  Shared evaluation (4 streams, ragged chunks) vs the float64 oracle, forward and all gradients."""
+    from goldsrl import _ffi, _ffi_net
+    E = 6
+    eng = _ffi.Engine(_ffi.ENV_SWARM, E, seed=3)
+    eng.reset()
+    rng = np.random.RandomState(11)
+    edge = [0, 1, 2, 3, 4, 79, 80, 81, 82, 83]
+    lb = rng.randint(0, 84, size=(E, 80, 2)).astype(np.uint8)
+    ab = np.zeros((E, 10, 2), np.uint8)
+    pos = np.zeros((E, 10, 2), np.uint8)
+    for e in range(E):
+        for a in range(10):
+            p = (rng.choice(edge), rng.choice(edge)) if (a + e) % 3 else (rng.randint(0, 84), rng.choice(edge))
+            ab[e, a] = p
+            pos[e, a] = p
+    pos[0, :4] = (0, 0); ab[0, :4] = (0, 0)              # four agents on one corner pixel
+    pos[1, :3] = (83, 83); ab[1, :3] = (83, 83)
+    pos[2, 0] = (0, 83); pos[2, 1] = (83, 0); ab[2, :2] = pos[2, :2]
+    lb[3, :40] = (5, 5); lb[4, :10] = (83, 0)            # piled-up locusts
+    lb[5, :6] = 255                                      # outside the box: no bin
+    ab[5, 0] = 255                                       # agent outside the box: no entry in the agent grid; one-hot clamped (quirk Q3)
+    states = []
+    for e in range(E):
+        l, a = lb[e].astype(int), ab[e].astype(int)
+        l[l[:, 0] == 255] = -1; a[a[:, 0] == 255] = -1
+        states.append(O.swarm_local_states(O.swarm_grid_from_compact(l, a, 84), pos[e]))
+    states = np.concatenate(states).astype(np.float32).astype(np.float64)
+    flat = _ffi_net.glorot_uniform_flat(seed=3).astype(np.float64)
+    p = NN.unflatten_params(flat)
+    for k in p:
+        if k.endswith("_b"):
+            p[k] = rng.normal(size=p[k].shape) * 0.05
+    flat = NN.flatten_params(p).astype(np.float32)
+    p = NN.unflatten_params(flat.astype(np.float64))
+    act, adv, y = _train_inputs(E, seed=4)
+    mu, sigma, vs = NN.conv_forward(p, states, 1000.0)
+    loss, pl, cl, g, _ = NN.conv_loss_and_grads(p, states, act.astype(np.float64), adv.astype(np.float64), y.astype(np.float64), 0.02, 1000.0)
+    for flags in (0, 1):
+        net = _ffi_net.ConvNet(eng, max_chunk_samples=40, reserved=flags)      # chunks of 4, 2 envs
+        net.set_params(flat)
+        out = net.predict_obs(lb, ab, pos)
+        np.testing.assert_allclose(out["mu"], mu, rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(out["sigma"], sigma, rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(out["vs"], vs, rtol=2e-4, atol=2e-3)
+        st = net.train_obs(lb, ab, pos, act, adv, y, lr=0.0, apply_update=False)
+        np.testing.assert_allclose(st["loss"], loss, rtol=1e-4)
+        got = NN.unflatten_params(net.get_grads().astype(np.float64))
+        for name, _ in NN.CONV_PARAM_SHAPES:
+            err = np.abs(got[name] - g[name]).max() / (np.abs(g[name]).max() + 1e-12)
+            assert err < 2e-4, (flags, name, err)
+        net.close()
