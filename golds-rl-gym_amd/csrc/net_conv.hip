@@ -69,6 +69,7 @@ struct NetLane {
     float *a3sh, *d3, *v3, *ysh;
     float *gd1sh, *gsh3, *g3p, *dz3p;     // gradient side: per-env sum of gd1, its dense1 data gradient, per-agent patch gradients
     int *perm, *goffp, *blkcnt, *blkoff, *sbeg, *send, *sgrp;
+    int *sbase, *rowagent, *sblk;      // compact slot rows (net_shared.inc): prefix of per-sample slot counts, row -> sample, scan scratch
     signed char *tilegroup, *org;
     signed char *ulist;
     float *slab;               // split-M partial sums
@@ -394,7 +395,13 @@ static int forward_chunk(grl_net *net, const uint8_t *lb, const uint8_t *ab, con
     net->last_n = n;
     if (net->shared_trunk) {
         // gradient step on resident activations: at level 2 the trunk tensors are resident too, only the group sort reruns
-        int rc = reuse_tail && net->keep_level >= 2 ? patch_sort(net, n) : forward_conv12_shared(net, lb, ab, pos, nenv);
+        int rc;
+        if (reuse_tail && net->keep_level >= 2) {
+            if ((rc = slot_index(net, pos, n))) return rc;
+            rc = patch_sort(net, n);
+        } else {
+            rc = forward_conv12_shared(net, lb, ab, pos, nenv);
+        }
         if (rc) return rc;
     } else {
     hipLaunchKernelGGL(conv1_sparse_kernel, dim3(nenv), dim3(256), 0, st, lb, ab, pos, P + ConvOffsets::c1w, P + ConvOffsets::c1b,
@@ -478,6 +485,9 @@ static int alloc_lane_forward(grl_net *n) {
     if (rc == GRL_OK) rc = nalloc(n, &n->blkoff, ((c + 255) / 256) * 9);
     if (rc == GRL_OK) rc = nalloc(n, &n->tilegroup, (size_t)n->ptiles);
     if (rc == GRL_OK) rc = nalloc(n, &n->org, c);
+    if (rc == GRL_OK) rc = nalloc(n, &n->sbase, c + 1);
+    if (rc == GRL_OK) rc = nalloc(n, &n->rowagent, c * 9);
+    if (rc == GRL_OK) rc = nalloc(n, &n->sblk, 1024);
     return rc;
 }
 
@@ -701,7 +711,7 @@ static int read_activation_impl(grl_net *n, const char *which, float *host, size
         if (n->last_n <= 0) return nfail(n, GRL_E_STATE, "grl_net_read_activation: no forward pass yet");
         float *tmp = nullptr;
         NET_HIP(n, hipMalloc((void **)&tmp, need_a));
-        hipLaunchKernelGGL(materialize_a2_kernel, dim3(n->last_n), dim3(256), 0, n->h->stream, n->a2sh, n->v2s, n->ulist, tmp);
+        hipLaunchKernelGGL(materialize_a2_kernel, dim3(n->last_n), dim3(256), 0, n->h->stream, n->a2sh, n->v2s, n->ulist, n->sbase, tmp);
         hipError_t e1 = hipStreamSynchronize(n->h->stream), e2 = hipMemcpy(host, tmp, bytes, hipMemcpyDeviceToHost);
         (void)hipFree(tmp);
         if (e1 != hipSuccess || e2 != hipSuccess) return nfail(n, GRL_E_HIP, "grl_net_read_activation: expanding a2 failed");

@@ -147,6 +147,7 @@ struct DenseRows {   // plain row-major [rows][ld], reduction length k
     static constexpr bool kRelu = false;
     const float *base;
     int rows, ld, k;
+    const int *rows_dev = nullptr;      // optional: the live row count on the device (tiles past it exit; rows is the bound)
     __device__ __forceinline__ int K() const { return k; }
     __device__ __forceinline__ void row(int r, long &off, int &iy0, int &ix0) const {
         off = (long)r * ld;
@@ -158,7 +159,7 @@ struct DenseRows {   // plain row-major [rows][ld], reduction length k
     }
     __device__ __forceinline__ bool ok(int, int, int, int) const { return true; }
     __device__ __forceinline__ bool tile_ok(int, int) const { return true; }
-    __device__ __forceinline__ bool tile_active(int) const { return true; }
+    __device__ __forceinline__ bool tile_active(int m0) const { return !rows_dev || m0 < *rows_dev; }
     __device__ __forceinline__ int bk(int k0, int) const { return k0; }
     __device__ __forceinline__ int bn(int n0, int) const { return n0; }
     __device__ __forceinline__ int rowidx(int m) const { return m; }
@@ -167,15 +168,19 @@ struct DenseRows {   // plain row-major [rows][ld], reduction length k
 };
 
 // Same on the patch-compact per-agent dz3 (net_patch.inc): base[n][py][px][co] (5x5 window with origin org[n] = oy*3+ox);
-// every pixel u - 2 + t inside the 7x7 map lies inside the agent's window by construction.
+// every pixel u - 2 + t inside the 7x7 map lies inside the agent's window by construction.  Rows are the COMPACT slot
+// rows (only the touched pixels an agent really has, 6.25 on average instead of 9): rowagent[r] names the sample.
 struct SlotGatherT3P {
     static constexpr bool kRelu = false;
     const float *base;
     const signed char *ulist, *org;
-    int rows;
+    int rows;                    // upper bound (9 per sample); the live count is *rows_dev
+    const int *rowagent;         // compact slot row -> sample
+    const int *rows_dev;
     __device__ __forceinline__ int K() const { return 576; }
     __device__ __forceinline__ void row(int r, long &off, int &iy0, int &ix0) const {
-        const int n = r / 9, u = ulist[r], g = org[n];
+        const bool live = r < *rows_dev;
+        const int n = live ? rowagent[r] : 0, u = live ? ulist[r] : -1, g = org[n];
         const int qy = u / 9, qx = u - qy * 9, oy = g / 3, ox = g - oy * 3;
         iy0 = u < 0 ? -16 : qy - 2;
         ix0 = u < 0 ? -16 : qx - 2;
@@ -192,13 +197,17 @@ struct SlotGatherT3P {
         return (unsigned)(iy0 + ty) < 7u && (unsigned)(ix0 + tx) < 7u;
     }
     __device__ __forceinline__ bool tile_ok(int, int) const { return true; }
-    __device__ __forceinline__ bool tile_active(int) const { return true; }
+    __device__ __forceinline__ bool tile_active(int m0) const { return m0 < *rows_dev; }
     __device__ __forceinline__ int bk(int k0, int) const { return k0; }
     __device__ __forceinline__ int bn(int n0, int) const { return n0; }
     __device__ __forceinline__ int rowidx(int m) const { return m; }
     __device__ __forceinline__ void rowp(int p, long &off, int &iy0, int &ix0) const { row(p, off, iy0, ix0); }
-    __device__ __forceinline__ void mrange(int z, int mc, int &mbeg, int &mend) const { mbeg = z * mc; mend = min(rows, mbeg + mc); }
+    __device__ __forceinline__ void mrange(int z, int mc, int &mbeg, int &mend) const {
+        mbeg = z * mc;
+        mend = min(*rows_dev, mbeg + mc);
+    }
 };
+
 
 // dense1 on the shared a3 (net_patch.inc): an agent's a3 differs from its env's a3sh only inside a 5x5 window ("patch",
 // origin (oy, ox) in {0,1,2}^2 = group g) of the 7x7 map.  Samples are sorted by group into 256-row tiles (perm[slot] =
