@@ -108,41 +108,6 @@ struct ConvGatherPM {
     __device__ __forceinline__ void mrange(int z, int mc, int &mbeg, int &mend) const { mbeg = z * mc; mend = min(rows, mbeg + mc); }
 };
 
-// conv3's transposed convolution evaluated only at the <= 9 conv2 pixels an agent's one-hot can reach:
-// row r = (sample n = r/9, slot r%9) with pixel u = ulist[r] of the 9x9 map (or -1: empty slot, all taps invalid);
-// k = (ty, tx, co) reads dz3[n][uy-2+ty][ux-2+tx][co] like ConvGather<9,9,1,1,-2,-2,3,3,64,7,7,true>.
-struct SlotGatherT3 {
-    static constexpr bool kRelu = false;
-    const float *base;
-    const signed char *ulist;
-    int rows;
-    __device__ __forceinline__ int K() const { return 576; }
-    __device__ __forceinline__ void row(int r, long &off, int &iy0, int &ix0) const {
-        const int n = r / 9, u = ulist[r];
-        const int qy = u / 9, qx = u - qy * 9;
-        iy0 = u < 0 ? -16 : qy - 2;
-        ix0 = u < 0 ? -16 : qx - 2;
-        off = (long)n * (49 * 64) + ((long)iy0 * 7 + ix0) * 64;
-    }
-    __device__ __forceinline__ void tap(int k0, int &toff, int &ty, int &tx) const {
-        int t = k0 >> 6;
-        int c0 = k0 & 63;
-        ty = t / 3;
-        tx = t - ty * 3;
-        toff = (ty * 7 + tx) * 64 + c0;
-    }
-    __device__ __forceinline__ bool ok(int iy0, int ix0, int ty, int tx) const {
-        return (unsigned)(iy0 + ty) < 7u && (unsigned)(ix0 + tx) < 7u;
-    }
-    __device__ __forceinline__ bool tile_ok(int, int) const { return true; }
-    __device__ __forceinline__ bool tile_active(int) const { return true; }
-    __device__ __forceinline__ int bk(int k0, int) const { return k0; }
-    __device__ __forceinline__ int bn(int n0, int) const { return n0; }
-    __device__ __forceinline__ int rowidx(int m) const { return m; }
-    __device__ __forceinline__ void rowp(int p, long &off, int &iy0, int &ix0) const { row(p, off, iy0, ix0); }
-    __device__ __forceinline__ void mrange(int z, int mc, int &mbeg, int &mend) const { mbeg = z * mc; mend = min(rows, mbeg + mc); }
-};
-
 struct DenseRows {   // plain row-major [rows][ld], reduction length k
     static constexpr bool kRelu = false;
     const float *base;
@@ -167,7 +132,10 @@ struct DenseRows {   // plain row-major [rows][ld], reduction length k
     __device__ __forceinline__ void mrange(int z, int mc, int &mbeg, int &mend) const { mbeg = z * mc; mend = min(rows, mbeg + mc); }
 };
 
-// Same on the patch-compact per-agent dz3 (net_patch.inc): base[n][py][px][co] (5x5 window with origin org[n] = oy*3+ox);
+// conv3's transposed convolution evaluated only at the <= 9 conv2 pixels ("slots") an agent's one-hot can reach: row r is one
+// slot with pixel u = ulist[r] of the 9x9 map; k = (ty, tx, co) reads dz3[n][uy-2+ty][ux-2+tx][co] like
+// ConvGather<9,9,1,1,-2,-2,3,3,64,7,7,true>.  The source is the patch-compact per-agent dz3 (net_patch.inc):
+// base[n][py][px][co] (5x5 window with origin org[n] = oy*3+ox);
 // every pixel u - 2 + t inside the 7x7 map lies inside the agent's window by construction.  Rows are the COMPACT slot
 // rows (only the touched pixels an agent really has, 6.25 on average instead of 9): rowagent[r] names the sample.
 struct SlotGatherT3P {
