@@ -362,3 +362,27 @@ def test_border_and_corner_agents_forward_and_gradients_match_oracle():
             err = np.abs(got[name] - g[name]).max() / (np.abs(g[name]).max() + 1e-12)
             assert err < 2e-4, (flags, name, err)
         net.close()
+
+
+def test_overfit_fixed_batch_like_reference_train_test():
+    """tests/estimators_tests.py:78-129 (ConvSingleAgentTest.train_test): 100 optimiser steps on ONE fixed batch of 10 agent
+    images with advantages 1/(idx+1) and critic targets -0.5*U(0,1), entropy 0, scale 1; afterwards critic_loss_mean and
+    policy_loss are 0 to one decimal place.  (The reference steps RMSProp(0.02) over a 3-action net; the device net has the
+    script's 2 actions and Adam, so the step size differs: Adam 1e-3.)  Also pins predict's shapes (:23-76)."""
+    from goldsrl import _ffi, _ffi_net
+    eng = _ffi.Engine(_ffi.ENV_SWARM, 1, seed=1692)
+    eng.reset()
+    net = _ffi_net.ConvNet(eng, max_chunk_samples=10, scale=1.0, entropy_beta=0.0, clip_norm=40.0)
+    net.set_params(_ffi_net.glorot_uniform_flat(seed=1))
+    obs = (eng.read("locust_bins"), eng.read("agent_bins"), eng.read("positions"))
+    pred = net.predict_obs(*obs)
+    assert pred["mu"].shape == (10, 2) and pred["sigma"].shape == (10, 2) and pred["vs"].shape == (10,)
+    rng = np.random.RandomState(1692)
+    actions = rng.uniform(size=(10, 2)).astype(np.float32)
+    st = None
+    for idx in range(100):
+        adv = (np.ones(10) / (idx + 1)).astype(np.float32)
+        tgt = (-0.5 * rng.uniform(size=10)).astype(np.float32)
+        st = net.train_obs(*obs, actions, adv, tgt, lr=1e-3, apply_update=True)
+    assert abs(st["critic_loss_mean"]) < 0.05 and abs(st["policy_loss"]) < 0.05, st
+    net.close()
