@@ -19,6 +19,8 @@ class ActorLearner(object):
         self.checkpoint_every = getattr(args, 'checkpoint_every', 0)    # updates between flat-weights checkpoints (0: never)
         self.checkpoint_path = getattr(args, 'checkpoint_path', 'checkpoint.npz')
         self.resume = getattr(args, 'resume', None)
+        self.summary_writer = None      # created by train() when args.summaries is set (actor_learner.py:79-83)
+        self.summaries = bool(getattr(args, 'summaries', False))
         self.network_creator = network_creator
         self.environment_creator = environment_creator
         self.network = network_creator()
@@ -37,6 +39,23 @@ class ActorLearner(object):
         if self.global_step <= self.lr_annealing_steps:
             return self.initial_lr - (self.global_step * self.initial_lr / self.lr_annealing_steps)
         return 0.0
+
+    def _open_summaries(self):
+        if self.summaries and self.summary_writer is None:
+            from .policy_monitor import ScalarWriter
+            self.summary_writer = ScalarWriter(self.debugging_folder)
+        return self.summary_writer
+
+    def _log_update(self, stats):
+        """'global_norm' (actor_learner.py:83) and the loss terms of one update, keyed by global_step."""
+        w = self.summary_writer
+        if w is None or not stats:
+            return
+        w.add_scalar("global_norm", stats["global_norm"], self.global_step)
+        w.add_scalar("loss/total", stats["loss"], self.global_step)
+        w.add_scalar("loss/policy", stats["policy_loss"], self.global_step)
+        w.add_scalar("loss/critic_mean", stats["critic_loss_mean"], self.global_step)
+        w.flush()
 
     def save_checkpoint(self, path):
         """Flat-weights checkpoint of the bound estimator + global_step (the reference's Saver path, actor_learner.py:70-89,

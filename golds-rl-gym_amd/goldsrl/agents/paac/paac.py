@@ -31,6 +31,7 @@ class PAACLearner(ActorLearner):
         net = self.network.net
         if self.resume:
             self.load_checkpoint(self.resume)
+        self._open_summaries()
         counter, global_step_start, start_time = 0, self.global_step, time.time()
         stats = None
         while self.global_step < self.max_global_steps:
@@ -38,6 +39,7 @@ class PAACLearner(ActorLearner):
             net.rollout(self.max_local_steps)
             self.global_step += self.max_local_steps * self.emulator_counts      # paac.py:149
             stats = net.train_rollout(self.get_lr())
+            self._log_update(stats)
             counter += 1
             if counter % max(1, int(5048 / self.emulator_counts)) == 0:
                 curr_time = time.time()
@@ -84,8 +86,10 @@ class GridPAACLearner(PAACLearner):
             from .policy_monitor import ScalarWriter, SwarmPolicyMonitor
             pe = SwarmPolicyMonitor(env=make("Swarm-eval-v0"), global_policy_net=self.network,
                                     state_processor=SwarmStateProcessor(grid_size=self.network.height),
-                                    summary_writer=ScalarWriter(self.debugging_folder), saver=None, network_conf=self.network.conf,
+                                    summary_writer=self._open_summaries() or ScalarWriter(self.debugging_folder), saver=None,
+                                    network_conf=self.network.conf,
                                     learner=self)
+        self._open_summaries()
         logging.debug("Starting training at Step {}".format(self.global_step))
         counter, global_step_start, start_time = 0, self.global_step, time.time()
         stats = None
@@ -94,6 +98,7 @@ class GridPAACLearner(PAACLearner):
             net.rollout(self.max_local_steps, layout)
             self.global_step += self.max_local_steps * self.emulator_counts      # global_step += 1 per env per step (paac.py:341)
             stats = net.train_rollout(self.get_lr())
+            self._log_update(stats)
             counter += 1
             if pe is not None and time.time() - last_eval >= eval_every:
                 pe.eval_once(max_sequence_length=self.rnn_length)

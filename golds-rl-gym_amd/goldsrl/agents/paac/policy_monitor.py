@@ -19,24 +19,36 @@ from .policy_v_network import ConvSingleAgentPolicyNetwork, FlatPolicyVNetwork
 
 
 class ScalarWriter(object):
-    """Stand-in for tf.summary.FileWriter: one JSON object per scalar in <logdir>/scalars.jsonl."""
+    """Stand-in for tf.summary.FileWriter: every scalar goes to <logdir>/scalars.jsonl (one JSON object per line) and to a
+    TensorBoard event file (events.out.tfevents.*, written by goldsrl.utils_tfevents without TensorFlow)."""
 
-    def __init__(self, logdir):
+    def __init__(self, logdir, tfevents=True):
         self.logdir = os.path.abspath(logdir)
         os.makedirs(self.logdir, exist_ok=True)
         self._f = open(os.path.join(self.logdir, "scalars.jsonl"), "a")
+        self._ev = None
+        if tfevents:
+            from ...utils_tfevents import EventFileWriter
+            self._ev = EventFileWriter(self.logdir)
 
     def get_logdir(self):
         return self.logdir
 
     def add_scalar(self, tag, value, step):
-        self._f.write(json.dumps({"tag": tag, "value": float(value), "step": int(step), "time": time.time()}) + "\n")
+        now = time.time()
+        self._f.write(json.dumps({"tag": tag, "value": float(value), "step": int(step), "time": now}) + "\n")
+        if self._ev is not None:
+            self._ev.add_scalar(tag, value, step, wall_time=now)
 
     def flush(self):
         self._f.flush()
+        if self._ev is not None:
+            self._ev.flush()
 
     def close(self):
         self._f.close()
+        if self._ev is not None:
+            self._ev.close()
 
 
 class PolicyMonitor(object):

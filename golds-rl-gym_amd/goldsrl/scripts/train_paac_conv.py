@@ -76,6 +76,8 @@ def get_arg_parser():
     p.add_argument('--checkpoint-every', default=0, type=int, dest="checkpoint_every", help="updates between flat-weights checkpoints")
     p.add_argument('--checkpoint-path', default='checkpoint.npz', type=str, dest="checkpoint_path")
     p.add_argument('--resume', default=None, type=str, help="flat-weights checkpoint to start from")
+    p.add_argument('--summaries', default=True, type=bool_arg,
+                   help="write global_norm / loss scalars per update to <debugging_folder> (JSON lines + TensorBoard event file)")
     return p
 
 

@@ -174,7 +174,12 @@ def test_grid_paac_learner_runs_updates(tmp_path):
     # the monitor played an eval episode after every update, and the last checkpoint resumes the run
     import json
     tags = [json.loads(l)["tag"] for l in open(tmp_path / "logs" / "scalars.jsonl")]
-    assert tags.count("eval/total_reward") == 2 and tags.count("eval/episode_length") == 2
+    assert tags.count("eval/total_reward") == 2 and tags.count("eval/episode_length") == 2 and tags.count("global_norm") == 2
+    # ... and the same scalars sit in a TensorBoard event file (actor_learner.py:79-83 writes them with tf.summary.FileWriter)
+    import glob
+    from goldsrl import utils_tfevents
+    ev = utils_tfevents.read_scalars(glob.glob(str(tmp_path / "logs" / "events.out.tfevents.*"))[0])
+    assert [t for t, _, _, _ in ev].count("global_norm") == 2 and {s for _, _, s, _ in ev} == {320, 640}
     args2 = S.get_arg_parser().parse_args(["-ec", "64", "--max_local_steps", "5", "--max_global_steps", "960", "--eval-every", "0",
                                            "--resume", ckpt])
     nc2, ec2 = S.get_network_and_environment_creator(args2)
