@@ -386,3 +386,32 @@ def test_overfit_fixed_batch_like_reference_train_test():
         st = net.train_obs(*obs, actions, adv, tgt, lr=1e-3, apply_update=True)
     assert abs(st["critic_loss_mean"]) < 0.05 and abs(st["policy_loss"]) < 0.05, st
     net.close()
+
+
+def test_odd_sizes_ragged_chunks_over_lanes():
+    """33 envs in chunks of 7 (five chunks, the last with 5 envs, dealt to 4 streams) against one 330-sample chunk of the plain
+    per-agent evaluation: forward bit-identical per sample is not expected across the two paths, agreement to round-off is."""
+    from goldsrl import _ffi, _ffi_net
+    E = 33
+    eng = _ffi.Engine(_ffi.ENV_SWARM, E, seed=9)
+    eng.reset()
+    rng = np.random.RandomState(2)
+    eng.step(O.swarm_transform_actions(rng.normal(size=(E, 10, 2)).astype(np.float32)))
+    obs = (eng.read("locust_bins"), eng.read("agent_bins"), eng.read("positions"))
+    flat = _ffi_net.glorot_uniform_flat(seed=5) + (rng.normal(size=2210213) * 0.01).astype(np.float32)
+    act, adv, y = _train_inputs(E, seed=6)
+    res = []
+    for chunk, flags in ((70, 0), (330, 1)):
+        net = _ffi_net.ConvNet(eng, max_chunk_samples=chunk, reserved=flags)
+        net.set_params(flat)
+        out = net.predict_obs(*obs)
+        st = net.train_obs(*obs, act, adv, y, lr=0.0, apply_update=False)
+        res.append((out, st, net.get_grads().astype(np.float64)))
+        net.close()
+    for k in ("mu", "sigma", "vs"):
+        np.testing.assert_allclose(res[0][0][k], res[1][0][k], rtol=2e-4, atol=2e-5 if k != "vs" else 2e-3)
+    np.testing.assert_allclose(res[0][1]["loss"], res[1][1]["loss"], rtol=1e-5)
+    a, b = NN.unflatten_params(res[0][2]), NN.unflatten_params(res[1][2])
+    for name, _ in NN.CONV_PARAM_SHAPES:
+        err = np.abs(a[name] - b[name]).max() / (np.abs(b[name]).max() + 1e-12)
+        assert err < 5e-5, (name, err)
