@@ -177,6 +177,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "GRL_BENCH_FORCE_DEVICE" in os.environ:      # rehearsal of the N > 1 control flow on a one-GPU box only
+        local_rank = int(os.environ["GRL_BENCH_FORCE_DEVICE"])
     dist = None
     if world > 1:
         import torch
