@@ -194,16 +194,41 @@ def main():
     eng.reset()
 
     net = None
+    exchange = "none"
     if args.policy == "conv":
         from goldsrl import rollout as R
         roll = R.ConvPolicyRollout(eng, T, train=not args.no_train, reserved=4 if args.single_stream else 0)
         net = roll.net
         if world > 1:
-            uid = net.comm_unique_id() if rank == 0 else np.zeros(net.comm_unique_id().size, np.uint8)
-            t = torch.from_numpy(uid)
-            dist.broadcast(t, src=0)
-            net.comm_init(t.numpy(), rank, world)     # RCCL over xGMI: one gradient all-reduce per update
-            net.comm_broadcast_params(0)
+            # one RCCL communicator over the ranks (xGMI); if any rank cannot form it, every rank falls back to summing the
+            # 8.8 MB gradient on the host through gloo -- slower, same mathematics (parameters stay replicated)
+            ok = 1
+            try:
+                uid = net.comm_unique_id() if rank == 0 else np.zeros(net.comm_unique_id().size, np.uint8)
+                t = torch.from_numpy(uid)
+                dist.broadcast(t, src=0)
+                net.comm_init(t.numpy(), rank, world)
+            except Exception as e:       # noqa: BLE001 -- any failure means "no device communicator"
+                sys.stderr.write("rank %d: RCCL communicator unavailable (%s)\n" % (rank, e))
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag[0]) == 1:
+                net.comm_broadcast_params(0)
+                exchange = "rccl"
+            else:
+                if ok:
+                    net.comm_destroy()
+                pt = torch.from_numpy(net.get_params())
+                dist.broadcast(pt, src=0)
+                net.set_params(pt.numpy())
+
+                def host_allreduce(g):
+                    tg = torch.from_numpy(np.ascontiguousarray(g))
+                    dist.all_reduce(tg, op=dist.ReduceOp.SUM)
+                    return tg.numpy(), world
+                roll.host_allreduce = host_allreduce
+                exchange = "gloo-host-fallback"
     else:
         roll = RandomPolicyRollout(eng, T)
 
@@ -287,7 +312,8 @@ def main():
                                    "(BASELINE configs[2])" % (E, T),
                        "envs_per_gpu": E, "rollout_steps": T, "policy": args.policy, "train": args.policy == "conv" and not args.no_train,
                        "swarm_math": "fast" if args.fast_math else "exact", "env_state_dtype": "f64", "stages": stages,
-                       "streams": 1 if (args.single_stream or args.policy != "conv") else 4},
+                       "streams": 1 if (args.single_stream or args.policy != "conv") else 4,
+                       "gradient_exchange": exchange},
         }
         if gemm is not None:
             launches, ms, flops = gemm

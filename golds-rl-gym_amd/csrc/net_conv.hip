@@ -120,6 +120,7 @@ struct grl_net : NetLane {
     float *keep;
     size_t keep_slots;
     long param_version, keep_version;
+    float last_inv_total;      // 1 / samples of the last gradient pass (grl_net_apply_grads)
     // lanes
     NetLane lanes[GRL_MAX_LANES];
     hipStream_t lane_stream[GRL_MAX_LANES];      // [0] = the handle's stream

@@ -28,6 +28,9 @@ NET_SIGNATURES = {
     "grl_net_predict_obs": (C.c_int, [_P, _I, _P, _P, _P, _P, _P, _P]),
     "grl_net_rollout": (C.c_int, [_P, _I, _I]),
     "grl_net_train_rollout": (C.c_int, [_P, _F, _P]),
+    "grl_net_train_rollout_grads": (C.c_int, [_P, _P]),
+    "grl_net_set_grads": (C.c_int, [_P, _P, C.c_int64]),
+    "grl_net_apply_grads": (C.c_int, [_P, _F, _F, _P]),
     "grl_net_train_obs": (C.c_int, [_P, _I, _P, _P, _P, _P, _P, _P, _F, _I, _P]),
     "grl_net_read_rollout": (C.c_int, [_P, C.c_char_p, _P, _SZ]),
     "grl_net_read_activation": (C.c_int, [_P, C.c_char_p, _P, _SZ]),
@@ -179,6 +182,22 @@ class ConvNet(object):
         self._check(self.lib.grl_net_train_rollout(self.n, lr, _ffi._ptr(stats)))
         return dict(zip(("loss", "policy_loss", "critic_loss_mean", "global_norm"), stats.tolist()))
 
+    def train_rollout_grads(self):
+        """Loss + backward over the last rollout only: the local mean gradient stays in the net (get_grads)."""
+        stats = np.zeros(4, np.float32)
+        self._check(self.lib.grl_net_train_rollout_grads(self.n, _ffi._ptr(stats)))
+        return dict(zip(("loss", "policy_loss", "critic_loss_mean", "global_norm"), stats.tolist()))
+
+    def set_grads(self, flat):
+        a = np.ascontiguousarray(flat, dtype=np.float32)
+        self._check(self.lib.grl_net_set_grads(self.n, _ffi._ptr(a), a.size))
+
+    def apply_grads(self, lr, grad_scale=1.0):
+        """clip_by_global_norm(grad_scale * grads) + Adam(lr) on the gradient currently in the net."""
+        stats = np.zeros(4, np.float32)
+        self._check(self.lib.grl_net_apply_grads(self.n, lr, grad_scale, _ffi._ptr(stats)))
+        return dict(zip(("loss", "policy_loss", "critic_loss_mean", "global_norm"), stats.tolist()))
+
     def read_rollout(self, which, shape, dtype=np.float32):
         a = np.empty(shape, dtype)
         self._check(self.lib.grl_net_read_rollout(self.n, which.encode(), _ffi._ptr(a), a.nbytes))
@@ -204,6 +223,9 @@ class ConvNet(object):
 
     def comm_broadcast_params(self, root=0):
         self._check(self.lib.grl_net_comm_broadcast_params(self.n, root))
+
+    def comm_destroy(self):
+        self._check(self.lib.grl_net_comm_destroy(self.n))
 
     def profile_enable(self, on=True):
         self._check(self.lib.grl_net_profile_enable(self.n, 1 if on else 0))

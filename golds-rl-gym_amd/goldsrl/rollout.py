@@ -10,8 +10,16 @@ class ConvPolicyRollout(object):
         self.net = _ffi_net.ConvNet(eng, max_chunk_samples=chunk, **net_kw)
         self.net.set_params(_ffi_net.glorot_uniform_flat(seed))
         self.last_stats = None
+        self.host_allreduce = None      # callable(flat float32 gradient) -> summed gradient, world size: gradient exchange on the host
 
     def run(self):
         self.net.rollout(self.T, self.reward_layout)
-        if self.train:
-            self.last_stats = self.net.train_rollout(self.lr)
+        if not self.train:
+            return
+        if self.host_allreduce is None:
+            self.last_stats = self.net.train_rollout(self.lr)        # RCCL all-reduce inside when a communicator is attached
+        else:       # no device communicator: local gradient -> host exchange -> clip + Adam on the mean of the ranks' means
+            self.net.train_rollout_grads()
+            summed, world = self.host_allreduce(self.net.get_grads())
+            self.net.set_grads(summed)
+            self.last_stats = self.net.apply_grads(self.lr, 1.0 / world)

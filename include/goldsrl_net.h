@@ -80,6 +80,14 @@ int grl_net_rollout(grl_net *net, int32_t T, int32_t reward_layout);
  * [all-reduce over ranks if a communicator is attached], clip_by_global_norm, Adam(lr).
  * stats_host (may be NULL) receives {loss, policy_loss, critic_loss_mean, global_norm}. Synchronous. */
 int grl_net_train_rollout(grl_net *net, float lr, float *stats_host);
+/* The same in two halves, for callers that exchange or post-process gradients themselves (bench.py's fallback when no
+ * RCCL communicator can be formed sums them over ranks with torch.distributed/gloo on the host):
+ * _grads: loss + backward over the last rollout only -- the LOCAL mean gradient is left in the net (grl_net_get_grads), stats
+ *         are the local loss terms and the local gradient norm, nothing is updated;
+ * grl_net_set_grads: upload a flat gradient;  grl_net_apply_grads: clip_by_global_norm(grad_scale * grads) + Adam(lr). */
+int grl_net_train_rollout_grads(grl_net *net, float *stats_host);
+int grl_net_set_grads(grl_net *net, const float *host, int64_t n);
+int grl_net_apply_grads(grl_net *net, float lr, float grad_scale, float *stats_host);
 /* Gradient step on caller-supplied samples (tests; network.loss feed of paac.py:374-387):
  * compact observations for n_envs envs (n = 10*n_envs samples), actions (n,2), advantages (n,)
  * ALREADY divided by scale, critic_target (n,).  apply_update=0 only computes gradients. */

@@ -415,3 +415,35 @@ def test_odd_sizes_ragged_chunks_over_lanes():
     for name, _ in NN.CONV_PARAM_SHAPES:
         err = np.abs(a[name] - b[name]).max() / (np.abs(b[name]).max() + 1e-12)
         assert err < 5e-5, (name, err)
+
+
+def test_split_gradient_step_equals_fused_and_supports_host_exchange():
+    """grl_net_train_rollout == train_rollout_grads + apply_grads (same rollout, same parameters afterwards), and the host
+    exchange hook of ConvPolicyRollout (bench.py's fallback when no RCCL communicator exists) with a world of one."""
+    from goldsrl import _ffi, _ffi_net, rollout
+    outs = []
+    for mode in ("fused", "split", "hook"):
+        eng = _ffi.Engine(_ffi.ENV_SWARM, 16, seed=4)
+        eng.reset()
+        r = rollout.ConvPolicyRollout(eng, 3, train=True, lr=1e-3, chunk=40)
+        if mode == "fused":
+            r.run()
+        elif mode == "split":
+            r.net.rollout(3, 0)
+            local = r.net.train_rollout_grads()
+            g = r.net.get_grads()
+            assert local["global_norm"] > 0 and np.isfinite(g).all()
+            p_before = r.net.get_params()
+            r.net.set_grads(g)
+            r.last_stats = r.net.apply_grads(1e-3, 1.0)
+            assert not np.array_equal(p_before, r.net.get_params())
+        else:
+            r.host_allreduce = lambda g: (g.copy(), 1)
+            r.run()
+        eng.wait()
+        outs.append((r.net.get_params().copy(), r.last_stats))
+        r.net.close()
+    for p, st in outs[1:]:
+        assert np.array_equal(p[6144:], outs[0][0][6144:])
+        np.testing.assert_allclose(p[:6144], outs[0][0][:6144], rtol=1e-5, atol=1e-8)
+        np.testing.assert_allclose(list(st.values()), list(outs[0][1].values()), rtol=1e-6)
