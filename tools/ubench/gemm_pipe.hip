@@ -96,6 +96,70 @@ __global__ __launch_bounds__(256, 2) void k(const float *__restrict__ A, const f
     for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) for (int r = 0; r < 16; ++r) s += acc[a][b][r];
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
+
+// V4: 8 waves, 256 x 128 tile (wave tile 64 x 64 as above), single LDS buffer, 2 barriers per K-tile
+__global__ __launch_bounds__(512, 1) void k8(const float *__restrict__ A, const float *__restrict__ B, float *out, int nk, long amask) {
+    __shared__ __attribute__((aligned(16))) float As[256 * LD], Bs[128 * LD];
+    for (int i = threadIdx.x; i < 256 * LD; i += 512) As[i] = (float)(i % 7) * 0.25f;
+    for (int i = threadIdx.x; i < 128 * LD; i += 512) Bs[i] = (float)(i % 5) * 0.5f;
+    __syncthreads();
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lk = lane >> 5, wm = wave >> 1, wn = wave & 1;
+    const int trow = tid >> 3, tk4 = (tid & 7) * 4;      // 64 rows per pass
+    f32x16 acc[2][2];
+    for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const float *ap = As + (wm * 64 + lr) * LD + lk * 16, *bp = Bs + (wn * 64 + lr) * LD + lk * 16;
+    long aoff[4], boff[2];
+    for (int i = 0; i < 4; ++i) aoff[i] = (((long)blockIdx.x * 256 + trow + 64 * i) * 1600L) & amask;
+    for (int i = 0; i < 2; ++i) boff[i] = (long)(trow + 64 * i) * 3136L;
+    float4 ra[4], rb[2];
+    for (int i = 0; i < 4; ++i) ra[i] = make_float4(1, 2, 3, 4);
+    for (int i = 0; i < 2; ++i) rb[i] = make_float4(.1f, .2f, .3f, .4f);
+    for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<float4 *>(As + (trow + 64 * i) * LD + tk4) = ra[i];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<float4 *>(Bs + (trow + 64 * i) * LD + tk4) = rb[i];
+        __syncthreads();
+        const int toff = ((kt + 1) % 48) * 32;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const float4 *>(A + aoff[i] + toff + tk4);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) rb[i] = *reinterpret_cast<const float4 *>(B + boff[i] + toff + tk4);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 af[2], bf[2];
+            af[0] = *reinterpret_cast<const float4 *>(ap + q * 4); af[1] = *reinterpret_cast<const float4 *>(ap + 32 * LD + q * 4);
+            bf[0] = *reinterpret_cast<const float4 *>(bp + q * 4); bf[1] = *reinterpret_cast<const float4 *>(bp + 32 * LD + q * 4);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].x, bf[b].x, acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].y, bf[b].y, acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].z, bf[b].z, acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].w, bf[b].w, acc[a][b], 0, 0, 0);
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+    }
+    float s = 0.f;
+    for (int i = 0; i < 4; ++i) s += ra[i].x;
+    for (int i = 0; i < 2; ++i) s += rb[i].y;
+    for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) for (int r = 0; r < 16; ++r) s += acc[a][b][r];
+    out[blockIdx.x * 512 + threadIdx.x] = s;
+}
+template <int OCC> void run8(const char *name, const float *A, const float *B, float *out, int blocks, int nk) {
+    long amask = ((1L << 28) - 1) & ~3L;
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    hipLaunchKernelGGL(k8, dim3(blocks), dim3(512), 0, 0, A, B, out, nk, amask);
+    (void)hipEventRecord(e0); hipLaunchKernelGGL(k8, dim3(blocks), dim3(512), 0, 0, A, B, out, nk, amask); (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    double flops = (double)blocks * 8 * nk * 64.0 * 4096.0;
+    printf("%-70s blocks %6d nk %3d: %7.3f ms  %6.1f TFLOP/s\n", name, blocks, nk, ms, flops / ms / 1e9);
+}
 template <int V> void run(const char *name, const float *A, const float *B, float *out, int blocks, int nk) {
     long amask = ((1L << 28) - 1) & ~3L;
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
@@ -109,13 +173,14 @@ template <int V> void run(const char *name, const float *A, const float *B, floa
 int main() {
     float *A, *B, *out;
     (void)hipMalloc(&A, (1L << 28) * 4 + (1 << 20)); (void)hipMemset(A, 0, (1L << 28) * 4); (void)hipMalloc(&B, 128 * 3136 * 4 + 8192); (void)hipMemset(B, 0, 128 * 3136 * 4);
-    (void)hipMalloc(&out, 16384L * 256 * 4);
+    (void)hipMalloc(&out, 16384L * 512 * 4);
     for (int nk : {16, 48}) {
         int blocks = 1312;      // 40960+ rows / 128 x 4 N-tiles
         run<0>("V0 single buffer, 2 barriers per K-tile (as built)", A, B, out, blocks, nk);
         run<1>("V1 double buffer, 1 barrier, store after compute", A, B, out, blocks, nk);
         run<3>("V3 double buffer, 1 barrier, store mid-compute", A, B, out, blocks, nk);
         run<2>("V2 single buffer, BK = 64", A, B, out, blocks, nk);
+        run8<1>("V4 8 waves, 256 x 128 tile", A, B, out, blocks / 2, nk);
     }
     return 0;
 }
