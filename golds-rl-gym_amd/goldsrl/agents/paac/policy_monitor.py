@@ -89,6 +89,18 @@ class PolicyMonitor(object):
     def eval_once(self, sess=None, max_sequence_length=5):
         raise NotImplementedError
 
+    def _play(self, first_state, choose_action):
+        """One episode: `choose_action(state, t)` -> env action until the env reports done.  Returns the per-step rewards
+        and the actions taken."""
+        rewards, taken = [], []
+        state, done = first_state, False
+        while not done:
+            action = choose_action(state, len(rewards))
+            taken.append(action)
+            state, reward, done, _ = self.env.step(action)
+            rewards.append(reward)
+        return rewards, taken
+
     def _summaries(self, global_step, total_reward, episode_length, rewards):
         if self.summary_writer is not None:
             self.summary_writer.add_scalar("eval/total_reward", total_reward, global_step)
@@ -122,26 +134,21 @@ class SolowPolicyMonitor(PolicyMonitor):
 
     def eval_once(self, sess=None, max_sequence_length=5):
         global_step = self.copy_params()
-        histories = []
-        done = False
-        state = self.env.reset()
-        processed_state = self.state_processor.process_state(state)
-        histories.append(np.array(processed_state))
-        total_reward, episode_length, rewards = 0.0, 0, []
-        while not done:
+        window_rows = []       # processed states of the episode so far (the reference keeps the last 2*max_sequence_length)
+
+        def choose(state, t):
+            processed = self.state_processor.process_state(state)
+            window_rows.append(np.array(processed))
+            del window_rows[:-2 * max_sequence_length]
             # the estimator takes a fixed (1, rnn_length, 2) window; rows past the episode's start are zero
             # (dynamic_rnn's sequence_length = number of non-zero rows, a3c/estimators.py:11-15)
-            window = np.zeros((1, max_sequence_length, len(processed_state)), np.float32)
-            recent = histories[-max_sequence_length:]
+            window = np.zeros((1, max_sequence_length, len(processed)), np.float32)
+            recent = window_rows[-max_sequence_length:]
             window[0, :len(recent)] = np.array(recent)
-            action = self.get_action_from_policy(np.array([processed_state]), window, None, sess)
-            next_state, reward, done, _ = self.env.step(action)
-            processed_state = self.state_processor.process_state(next_state)
-            histories.append(np.array(processed_state))
-            total_reward += reward
-            episode_length += 1
-            rewards.append(reward)
-            histories = histories[-2 * max_sequence_length:]
+            return self.get_action_from_policy(np.array([processed]), window, None, sess)
+
+        rewards, _ = self._play(self.env.reset(), choose)
+        total_reward, episode_length = float(np.sum(rewards)), len(rewards)
         self._summaries(global_step, total_reward, episode_length, rewards)
         return total_reward, episode_length, rewards
 
@@ -170,21 +177,16 @@ class SwarmPolicyMonitor(PolicyMonitor):
     def eval_once(self, sess=None, max_sequence_length=5, actions=None):
         """`actions`: a queue.Queue of (10,2) arrays replayed instead of the policy (policy_monitor.py:173-176)."""
         global_step = self.copy_params()
-        done = False
-        self.env.reset()
-        total_reward, episode_length, rewards, taken_actions = 0.0, 0, [], []
-        while not done:
-            if not actions:
-                action = self.get_action_from_policy(None, None, None, sess)
-            else:
-                action = np.asarray(actions.get())
-            taken_actions.append(np.asarray(action).tolist())
-            _, reward, done, _ = self.env.step(action)
-            total_reward += reward
-            episode_length += 1
-            rewards.append(reward)
+
+        def choose(state, t):
+            if actions:
+                return np.asarray(actions.get())
+            return self.get_action_from_policy(None, None, None, sess)
+
+        rewards, taken = self._play(self.env.reset(), choose)
+        total_reward, episode_length = float(np.sum(rewards)), len(rewards)
         if total_reward > self.best_score:
             self.best_score = total_reward
-            self._save_actions(total_reward, taken_actions)
+            self._save_actions(total_reward, [np.asarray(a).tolist() for a in taken])
         self._summaries(global_step, total_reward, episode_length, rewards)
         return total_reward, episode_length, rewards

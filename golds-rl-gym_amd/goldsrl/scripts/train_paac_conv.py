@@ -14,13 +14,12 @@ from goldsrl.agents.state_processors import SwarmStateProcessor
 logging.basicConfig(stream=sys.stdout, level=logging.INFO)
 
 
-def bool_arg(string):
-    value = string.lower()
-    if value == 'true':
-        return True
-    elif value == 'false':
-        return False
-    raise argparse.ArgumentTypeError("Expected True or False, but got {}".format(string))
+def bool_arg(text):
+    """'true' / 'false' (any case) -> bool, as the reference's flag type does."""
+    table = {'true': True, 'false': False}
+    if text.lower() not in table:
+        raise argparse.ArgumentTypeError("Expected True or False, but got {}".format(text))
+    return table[text.lower()]
 
 
 def get_network_and_environment_creator(args, random_seed=3):
@@ -43,32 +42,39 @@ def get_network_and_environment_creator(args, random_seed=3):
     return network_creator, env_creator
 
 
+# (flag strings, dest, type, default): the reference script's options and defaults (scripts/train_paac_conv.py:95-121)
+_REFERENCE_FLAGS = (
+    (('-d', '--device'), 'device', str, '/gpu:0'),
+    (('--e',), 'e', float, 0.1),
+    (('--alpha',), 'alpha', float, 0.99),
+    (('-lr', '--initial_lr'), 'initial_lr', float, 1e-4),
+    (('-lra', '--lr_annealing_steps'), 'lr_annealing_steps', int, 80000000),
+    (('--entropy',), 'entropy_regularisation_strength', float, 0.02),
+    (('--clip_norm',), 'clip_norm', float, 40.0),
+    (('--clip_norm_type',), 'clip_norm_type', str, 'global'),
+    (('--gamma',), 'gamma', float, 0.99),
+    (('--max_global_steps',), 'max_global_steps', int, 80000000),
+    (('--max_local_steps',), 'max_local_steps', int, 5),
+    (('--single_life_episodes',), 'single_life_episodes', bool_arg, False),
+    (('-ec', '--emulator_counts'), 'emulator_counts', int, 32),
+    (('-ew', '--emulator_workers'), 'emulator_workers', int, 8),
+    (('-df', '--debugging_folder'), 'debugging_folder', str, 'logs/'),
+    (('-rs', '--random_start'), 'random_start', bool_arg, True),
+    (('--scale',), 'scale', float, 1000.0),
+    (('--height',), 'height', int, 84),
+    (('--filters',), 'filters', int, 32),
+    (('--rnn-length',), 'rnn_length', int, 5),
+    (('--static-size',), 'static_size', int, 2),
+    (('--temporal-size',), 'temporal_size', int, 2),
+    (('--static-hidden-size',), 'static_hidden_size', int, 32),
+    (('--temporal-hidden-size',), 'temporal_hidden_size', int, 32),
+)
+
+
 def get_arg_parser():
-    p = argparse.ArgumentParser()
-    p.add_argument('-d', '--device', default='/gpu:0', type=str, dest="device")
-    p.add_argument('--e', default=0.1, type=float, dest="e")
-    p.add_argument('--alpha', default=0.99, type=float, dest="alpha")
-    p.add_argument('-lr', '--initial_lr', default=0.0001, type=float, dest="initial_lr")
-    p.add_argument('-lra', '--lr_annealing_steps', default=80000000, type=int, dest="lr_annealing_steps")
-    p.add_argument('--entropy', default=0.02, type=float, dest="entropy_regularisation_strength")
-    p.add_argument('--clip_norm', default=40.0, type=float, dest="clip_norm")
-    p.add_argument('--clip_norm_type', default="global", dest="clip_norm_type")
-    p.add_argument('--gamma', default=0.99, type=float, dest="gamma")
-    p.add_argument('--max_global_steps', default=80000000, type=int, dest="max_global_steps")
-    p.add_argument('--max_local_steps', default=5, type=int, dest="max_local_steps")
-    p.add_argument('--single_life_episodes', default=False, type=bool_arg, dest="single_life_episodes")
-    p.add_argument('-ec', '--emulator_counts', default=32, type=int, dest="emulator_counts")
-    p.add_argument('-ew', '--emulator_workers', default=8, type=int, dest="emulator_workers")
-    p.add_argument('-df', '--debugging_folder', default='logs/', type=str, dest="debugging_folder")
-    p.add_argument('-rs', '--random_start', default=True, type=bool_arg, dest="random_start")
-    p.add_argument('--scale', default=1000., type=float)
-    p.add_argument('--height', default=84, type=int)
-    p.add_argument('--filters', default=32, type=int)
-    p.add_argument('--rnn-length', default=5, type=int)
-    p.add_argument('--static-size', default=2, type=int)
-    p.add_argument('--temporal-size', default=2, type=int)
-    p.add_argument('--static-hidden-size', default=32, type=int)
-    p.add_argument('--temporal-hidden-size', default=32, type=int)
+    p = argparse.ArgumentParser(description="PAAC on Swarm-v0 with the conv policy (device engine)")
+    for flags, dest, kind, default in _REFERENCE_FLAGS:
+        p.add_argument(*flags, dest=dest, type=kind, default=default)
     p.add_argument('--reward-layout', default='broadcast', choices=['broadcast', 'reference'], dest="reward_layout",
                    help="'reference' reproduces paac.py:331-338's (T, E*10) indexing (quirk Q4)")
     p.add_argument('--eval-every', default=30.0, type=float, dest="eval_every",
