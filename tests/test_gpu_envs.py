@@ -482,3 +482,53 @@ def test_create_errors_are_reported_not_thrown():
     with pytest.raises(f.GrlError) as ei:
         eng.get_state("SOLOW_K")
     assert ei.value.code == f.E_INVALID
+
+
+def test_flat_envs_full_size_properties():
+    """BASELINE sizes (configs 2 and 5): Solow 4 096 envs and TradeAR1-16 65 536 envs.  Size-independent properties:
+    sharding invariance (env i of a 2-way split equals env i of the full batch, bit for bit: generator streams are keyed by
+    the global env id), the Solow capital law k' = (1-delta) k + s y and the Trade accounting identity
+    assets' = cash' + sum(q' p) at the prices the trade was made at, reward = log(assets'+1e-4) - log(assets+1e-4)."""
+    f = ffi()
+    # ---- Solow, config 2
+    E = 4096
+    full = f.Engine(f.ENV_SOLOW, E, seed=1692, max_episode_steps=1024); full.reset()
+    halves = [f.Engine(f.ENV_SOLOW, E // 2, seed=1692, max_episode_steps=1024, env_id_offset=o) for o in (0, E // 2)]
+    for h in halves:
+        h.reset()
+    rng = np.random.RandomState(0)
+    for t in range(6):
+        k0 = full.read("obs_raw")[:, 0].astype(np.float64)
+        z0 = full.read("obs_raw")[:, 1].astype(np.float64)
+        s = (1.0 / (1.0 + np.exp(-rng.normal(size=(E, 1))))).astype(np.float32)
+        full.step(s)
+        for h, sl in zip(halves, (slice(0, E // 2), slice(E // 2, E))):
+            h.step(s[sl])
+        got = np.concatenate([h.read("obs_raw") for h in halves])
+        assert np.array_equal(got, full.read("obs_raw"))
+        assert np.array_equal(np.concatenate([h.read("reward") for h in halves]), full.read("reward"))
+        sv = np.maximum(1e-3, s[:, 0].astype(np.float64))
+        y = np.exp(z0) * k0 ** 0.33
+        np.testing.assert_allclose(full.read("obs_raw")[:, 0], (1 - 0.02) * k0 + sv * y, rtol=2e-5)       # fed_env.py:205-207
+        np.testing.assert_allclose(full.read("reward"), np.log((1 - sv) * y + 1e-4), rtol=1e-4, atol=1e-5)
+    # ---- TradeAR1-16, config 5
+    E, n = 65536, 16
+    full = trade_engine(E, n_assets=n, seed=77); full.reset()
+    halves = [trade_engine(E // 2, n_assets=n, seed=77, env_id_offset=o) for o in (0, E // 2)]
+    for h in halves:
+        h.reset()
+    for t in range(4):
+        raw0 = full.read("obs_raw").astype(np.float64)
+        assets_prev = full.get_state("TRADE_ASSETS").astype(np.float64).reshape(-1)      # valued at the previous step's prices
+        act = np.tanh(rng.normal(size=(E, n))).astype(np.float32)
+        full.step(act)
+        for h, sl in zip(halves, (slice(0, E // 2), slice(E // 2, E))):
+            h.step(act[sl])
+        raw = full.read("obs_raw")
+        assert np.array_equal(np.concatenate([h.read("obs_raw") for h in halves]), raw)
+        alive = ~full.read("done").astype(bool)
+        cash1, q1, p0 = raw[:, 0].astype(np.float64), raw[:, 1:1 + n].astype(np.float64), raw0[:, 1 + n:]
+        assets1 = cash1 + (q1 * p0).sum(axis=1)          # valued at the prices the trade was made at (fed_env.py:308-311)
+        rew = full.read("reward").astype(np.float64)
+        np.testing.assert_allclose(full.get_state("TRADE_ASSETS").reshape(-1)[alive], assets1[alive], rtol=2e-5)
+        np.testing.assert_allclose(rew[alive], (np.log(assets1 + 1e-4) - np.log(assets_prev + 1e-4))[alive], rtol=0, atol=2e-4)
