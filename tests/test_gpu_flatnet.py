@@ -85,8 +85,9 @@ def test_flat_adam_steps_match_oracle():
         np.testing.assert_allclose(net.get_params().astype(np.float64) - flat0, pf - flat0, rtol=0, atol=3e-5 * step)
 
 
-def test_flat_paac_rollout_on_solow_engine():
-    E, T = 256, 20
+@pytest.mark.parametrize("E", [256, 4096])      # 4 096 envs x 20 steps = BASELINE config 2
+def test_flat_paac_rollout_on_solow_engine(E):
+    T = 20
     eng, net = _net({"max_episode_steps": 8}, n_env=E, max_samples=E * T)
     p = _params(net)
     obs0, hist0 = eng.read("obs"), eng.read("history")
