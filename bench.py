@@ -249,11 +249,12 @@ def main():
     # GEMM roofline: one more update of the same workload with a HIP event pair around every gemm_rowk / gemm_tn launch.
     # Per-launch events need the launches serialised, so this pass runs on one stream; the timed region above alternates
     # independent chunks between four streams, where kernels of different chunks overlap and have no clean duration.
-    gemm, gemm_step_s = None, None
+    gemm, gemm_step_s, gemm_tags = None, None, {}
     if net is not None:
         net.profile_enable(True)
         gemm_step_s = timed(roll.run, eng.wait, 1)
         gemm = net.profile_read()
+        gemm_tags = net.profile_read_tags()
         net.profile_enable(False)
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64)
@@ -330,7 +331,10 @@ def main():
                                "measured": "HIP event pair around every GEMM launch of ONE extra update run right after the timed "
                                            "region on a single stream (%.1f ms); the timed region itself deals chunks round-robin "
                                            "to four streams (GRL_NET_F_SINGLE_STREAM off)" % (gemm_step_s * 1e3 if gemm_step_s else 0.0),
-                               "flops_per_launch_avg": flops / max(launches, 1)}
+                               "flops_per_launch_avg": flops / max(launches, 1),
+                               "by_family": {k: {"launches": v[0], "ms": v[1], "achieved": v[2] / (v[1] * 1e-3) / 1e12 if v[1] > 0 else 0.0,
+                                                 "frac": (v[2] / (v[1] * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS) if v[1] > 0 else 0.0}
+                                             for k, v in gemm_tags.items()}}
             out["roofline_env_step"] = env_roof
         else:
             out["roofline"] = env_roof

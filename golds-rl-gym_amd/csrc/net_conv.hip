@@ -107,6 +107,9 @@ struct grl_net : NetLane {
     std::vector<void *> allocs;
     bool prof_on;
     std::vector<hipEvent_t> prof_ev;
+    std::vector<unsigned char> prof_tag;     // GRL_PROF_TAG_* of every bracketed launch
+    std::vector<double> prof_launch_flops;
+    int prof_tag_cur;
     size_t prof_used;
     double prof_flops;
     int last_n;                // samples in the last chunk (for read_activation)
@@ -176,12 +179,29 @@ static int lanes_join(grl_net *net) {
     return GRL_OK;
 }
 
+// live compact slot rows of the chunk at hand -- read back only while profiling (the profiled pass is serialised anyway), so that
+// the slot GEMMs' FLOPs are counted on the rows they really process; otherwise the upper bound
+static double slot_rows_for_flops(grl_net *net, int n) {
+    if (!net->prof_on) return 9.0 * n;
+    int live = 9 * n;
+    if (hipStreamSynchronize(net->h->stream) == hipSuccess) (void)hipMemcpy(&live, net->sbase + n, sizeof(int), hipMemcpyDeviceToHost);
+    return (double)live;
+}
+
+// which family a bracketed GEMM launch belongs to (grl_net_profile_read_tags); set with net->prof_tag_cur before a group of launches
+enum {
+    PT_OTHER = 0, PT_DENSE_FWD, PT_DENSE_DGRAD, PT_DENSE_WGRAD, PT_PATCH_FWD, PT_PATCH_DGRAD, PT_PATCH_WGRAD, PT_ENV_FWD, PT_ENV_DGRAD,
+    PT_ENV_WGRAD, PT_SLOT_FWD, PT_SLOT_DGRAD, PT_SLOT_WGRAD, PT_CLASS_CORR, PT_PER_AGENT, PT_COUNT
+};
+
 struct GemmTimer {
     grl_net *n;
     GemmTimer(grl_net *net, double flops) : n(net) {
         if (n->prof_on && n->prof_used + 2 <= n->prof_ev.size()) {
             (void)hipEventRecord(n->prof_ev[n->prof_used], n->h->stream);
             n->prof_flops += flops;
+            n->prof_tag[n->prof_used / 2] = (unsigned char)n->prof_tag_cur;
+            n->prof_launch_flops[n->prof_used / 2] = flops;
         }
     }
     ~GemmTimer() {
@@ -405,6 +425,7 @@ static int forward_chunk(grl_net *net, const uint8_t *lb, const uint8_t *ab, con
         }
         if (rc) return rc;
     } else {
+    net->prof_tag_cur = PT_PER_AGENT;
     hipLaunchKernelGGL(conv1_sparse_kernel, dim3(nenv), dim3(256), 0, st, lb, ab, pos, P + ConvOffsets::c1w, P + ConvOffsets::c1b,
                        net->a1, net->h->cfg.grid_size, (float *)nullptr, (float *)nullptr);
     {
@@ -425,6 +446,7 @@ static int forward_chunk(grl_net *net, const uint8_t *lb, const uint8_t *ab, con
         hipLaunchKernelGGL((gemm_rowk<256, 64, 4, 1, GatherConv3, EpiBiasAct>), dim3(1, (n * 49 + 255) / 256), dim3(256), 0, st,
                            g, PT + ConvOffsets::c3w, 576, 64, e);
     }
+    net->prof_tag_cur = net->shared_trunk ? PT_DENSE_FWD : PT_PER_AGENT;
     auto dense = [&](const float *in, int K, const float *w, const float *b, int N, float *out) {
         DenseRows g{in, n, K, K};
         EpiBiasAct e{out, N, b, ACT_RELU};
@@ -538,7 +560,7 @@ int grl_net_create(grl_handle *h, const grl_net_config *cfg, grl_net **out) {
     hipSetDevice(h->cfg.device_id);
     grl_net *n = new grl_net();
     n->h = h; n->cfg = *cfg; n->chunk = cfg->max_chunk_samples; n->adam_t = 0;
-    n->T = 0; n->B = 0; n->tmp_envs = 0; n->act_counter = 0; n->prof_on = false; n->prof_used = 0; n->prof_flops = 0; n->last_n = 0;
+    n->T = 0; n->B = 0; n->tmp_envs = 0; n->act_counter = 0; n->prof_on = false; n->prof_used = 0; n->prof_flops = 0; n->last_n = 0; n->prof_tag_cur = 0;
     n->ro_lb = nullptr; n->slab_floats = 0; n->w3t = n->w2t = nullptr;
     n->mu = n->sigma = n->vs = nullptr;
     n->keep_level = 0;
@@ -751,6 +773,8 @@ int grl_net_profile_enable(grl_net *n, int32_t on) {
     NET_HIP(n, hipStreamSynchronize(n->h->stream));
     if (on && n->prof_ev.empty()) {
         n->prof_ev.resize(131072);   // 65 536 bracketed launches (~13 full updates at 32 768 envs)
+        n->prof_tag.assign(65536, 0);
+        n->prof_launch_flops.assign(65536, 0.0);
         for (auto &ev : n->prof_ev) NET_HIP(n, hipEventCreate(&ev));
     }
     n->prof_on = on != 0; n->prof_used = 0; n->prof_flops = 0;
@@ -768,6 +792,20 @@ int grl_net_profile_read(grl_net *n, int32_t *launches_out, float *total_ms_out,
         total += ms;
     }
     *launches_out = (int32_t)(n->prof_used / 2); *total_ms_out = total; *flops_out = n->prof_flops;
+    return GRL_OK;
+}
+
+int grl_net_profile_read_tags(grl_net *n, int32_t ntags, int32_t *launches, float *ms, double *flops) {
+    if (!n || !launches || !ms || !flops || ntags < PT_COUNT) return GRL_E_INVALID;
+    hipSetDevice(n->h->cfg.device_id);
+    NET_HIP(n, hipStreamSynchronize(n->h->stream));
+    for (int t = 0; t < ntags; ++t) { launches[t] = 0; ms[t] = 0.f; flops[t] = 0.0; }
+    for (size_t i = 0; i + 1 < n->prof_used; i += 2) {
+        float d = 0.f;
+        NET_HIP(n, hipEventElapsedTime(&d, n->prof_ev[i], n->prof_ev[i + 1]));
+        const int t = n->prof_tag[i / 2] < PT_COUNT ? n->prof_tag[i / 2] : 0;
+        launches[t] += 1; ms[t] += d; flops[t] += n->prof_launch_flops[i / 2];
+    }
     return GRL_OK;
 }
 

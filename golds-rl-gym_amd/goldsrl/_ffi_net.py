@@ -41,6 +41,7 @@ NET_SIGNATURES = {
     "grl_net_comm_destroy": (C.c_int, [_P]),
     "grl_net_profile_enable": (C.c_int, [_P, _I]),
     "grl_net_profile_read": (C.c_int, [_P, C.POINTER(_I), C.POINTER(C.c_float), C.POINTER(C.c_double)]),
+    "grl_net_profile_read_tags": (C.c_int, [_P, _I, _P, _P, _P]),
 }
 
 NET_CONV_SINGLE_AGENT = 0
@@ -229,6 +230,17 @@ class ConvNet(object):
 
     def profile_enable(self, on=True):
         self._check(self.lib.grl_net_profile_enable(self.n, 1 if on else 0))
+
+    PROFILE_TAGS = ("other", "dense_small_fwd", "dense_small_dgrad", "dense_small_wgrad", "dense1_patch_fwd", "dense1_patch_dgrad",
+                    "dense1_patch_wgrad", "per_env_fwd", "per_env_dgrad", "per_env_wgrad", "slot_products_fwd", "slot_dgrad", "slot_wgrad",
+                    "conv2_class_corrections", "per_agent_mode", "-")
+
+    def profile_read_tags(self):
+        """{family: (launches, ms, flops)} of the bracketed GEMM launches since profile_enable(True)."""
+        k = len(self.PROFILE_TAGS)
+        n, ms, fl = np.zeros(k, np.int32), np.zeros(k, np.float32), np.zeros(k, np.float64)
+        self._check(self.lib.grl_net_profile_read_tags(self.n, k, _ffi._ptr(n), _ffi._ptr(ms), _ffi._ptr(fl)))
+        return {name: (int(n[i]), float(ms[i]), float(fl[i])) for i, name in enumerate(self.PROFILE_TAGS) if n[i]}
 
     def profile_read(self):
         n, ms, fl = C.c_int32(), C.c_float(), C.c_double()

@@ -118,6 +118,10 @@ int grl_net_comm_destroy(grl_net *net);
  * of gemm_rowk / gemm_tn while enabled): returns launches, summed ms and summed FLOPs. */
 int grl_net_profile_enable(grl_net *net, int32_t on);
 int grl_net_profile_read(grl_net *net, int32_t *launches_out, float *total_ms_out, double *flops_out);
+/* The same per GEMM family (arrays of ntags >= 15 entries): 0 other, 1-3 small dense layers forward / data gradient / weight
+ * gradient, 4-6 dense1 patch GEMMs forward / data / weight, 7-9 once-per-env GEMMs forward / data / weight, 10-12 slot GEMMs
+ * (conv3 products / data / weight), 13 conv2 class corrections, 14 per-agent evaluation mode. */
+int grl_net_profile_read_tags(grl_net *net, int32_t ntags, int32_t *launches, float *ms, double *flops);
 
 #ifdef __cplusplus
 }
