@@ -132,6 +132,33 @@ struct DenseRows {   // plain row-major [rows][ld], reduction length k
     __device__ __forceinline__ void mrange(int z, int mc, int &mbeg, int &mend) const { mbeg = z * mc; mend = min(rows, mbeg + mc); }
 };
 
+// Two row-major [rows][ld] operands side by side along K (k < half from base, k >= half from base + delta), multiplied against
+// two weight matrices stacked the same way (Bt's k offset jumps by bdelta at k = half): dX = [dY1 | dY2] . [W1 | W2]^T in one
+// pass instead of two accumulating ones (pol1 / v1 both feed dense2's output).
+struct DenseRowsPair {
+    static constexpr bool kRelu = false;
+    const float *base;
+    int rows, ld, half;      // K() = 2 * half
+    int delta, bdelta;       // float offsets of the second operand / second weight matrix relative to the first
+    __device__ __forceinline__ int K() const { return 2 * half; }
+    __device__ __forceinline__ void row(int r, long &off, int &iy0, int &ix0) const {
+        off = (long)r * ld;
+        iy0 = ix0 = 0;
+    }
+    __device__ __forceinline__ void tap(int k0, int &toff, int &ty, int &tx) const {
+        toff = k0 < half ? k0 : delta + (k0 - half);
+        ty = tx = 0;
+    }
+    __device__ __forceinline__ bool ok(int, int, int, int) const { return true; }
+    __device__ __forceinline__ bool tile_ok(int, int) const { return true; }
+    __device__ __forceinline__ bool tile_active(int) const { return true; }
+    __device__ __forceinline__ int bk(int k0, int) const { return k0 < half ? k0 : bdelta + (k0 - half); }
+    __device__ __forceinline__ int bn(int n0, int) const { return n0; }
+    __device__ __forceinline__ int rowidx(int m) const { return m; }
+    __device__ __forceinline__ void rowp(int p, long &off, int &iy0, int &ix0) const { row(p, off, iy0, ix0); }
+    __device__ __forceinline__ void mrange(int z, int mc, int &mbeg, int &mend) const { mbeg = z * mc; mend = min(rows, mbeg + mc); }
+};
+
 // conv3's transposed convolution evaluated only at the <= 9 conv2 pixels ("slots") an agent's one-hot can reach: row r is one
 // slot with pixel u = ulist[r] of the 9x9 map; k = (ty, tx, co) reads dz3[n][uy-2+ty][ux-2+tx][co] like
 // ConvGather<9,9,1,1,-2,-2,3,3,64,7,7,true>.  The source is the patch-compact per-agent dz3 (net_patch.inc):
