@@ -26,6 +26,10 @@
 namespace grl {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#ifndef GRL_SCHED_FENCE
+#define GRL_SCHED_FENCE __builtin_amdgcn_sched_barrier(0);
+#endif
 
 // ---------------------------------------------------------------------------- gather descriptors
 // Row r of the (virtual) operand = output pixel (n, qy, qx); reduction index k = ((ty*P + tx)*C + c)
@@ -330,16 +334,51 @@ struct EpiGradStride2 {
     }
 };
 
+// ---------------------------------------------------------------------------- fp32 operands on the bf16 matrix pipe
+// x = h + m + l exactly: h = the upper 16 bits of x (truncation to bf16), m = the upper 16 bits of x - h, l = x - h - m
+// (<= 8 significant bits are left, so l is a bf16 number too).  Low halves of the returned dwords are garbage; pack2
+// keeps the upper halves only.
+__device__ __forceinline__ void split1(float x, unsigned &h, unsigned &m, unsigned &l) {
+    h = __float_as_uint(x);
+    const float r = x - __uint_as_float(h & 0xffff0000u);
+    m = __float_as_uint(r);
+    l = __float_as_uint(r - __uint_as_float(m & 0xffff0000u));
+}
+__device__ __forceinline__ unsigned pack2(unsigned lo, unsigned hi) {      // bf16 pair: element 0 = lo's upper half
+    return __builtin_amdgcn_perm(hi, lo, 0x07060302u);
+}
+// four consecutive-k values -> 4 bf16 per plane
+__device__ __forceinline__ void split4(float x0, float x1, float x2, float x3, uint2 &h, uint2 &m, uint2 &l) {
+    unsigned h0, h1, h2, h3, m0, m1, m2, m3, l0, l1, l2, l3;
+    split1(x0, h0, m0, l0);
+    split1(x1, h1, m1, l1);
+    split1(x2, h2, m2, l2);
+    split1(x3, h3, m3, l3);
+    h = make_uint2(pack2(h0, h1), pack2(h2, h3));
+    m = make_uint2(pack2(m0, m1), pack2(m2, m3));
+    l = make_uint2(pack2(l0, l1), pack2(l2, l3));
+}
+// acc += a * b with the six partial products of weight >= 2^-24 (smallest first)
+__device__ __forceinline__ void mfma_x6(f32x16 &acc, const bf16x8 (&a)[3], const bf16x8 (&b)[3]) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
+}
+constexpr int kLdh = 40;       // bf16 per LDS tile row: 32 + 8 pad (80 B) -> the 16 lanes of every ds_read_b128 group hit 16 distinct 4-bank slots
+
 // ---------------------------------------------------------------------------- C = A(rowk) * Bt^T
 template <int BM, int BN, int WGM, int WGN, class AG, class Epi>
 __global__ __launch_bounds__(256, 2) void gemm_rowk(AG ag, const float *__restrict__ Bt, int ldb, int N, Epi epi) {
-    constexpr int BK = 32, LD = 36;
+    constexpr int BK = 32, LDH = kLdh;
     constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
     constexpr int NA = BM / 32;                       // float4 per thread for the A tile
     constexpr int NB = BN / 32;                       // float4 per thread for the B tile
     static_assert(WGM * WGN == 4 && TM >= 1 && TN >= 1, "4 waves");
-    __shared__ __attribute__((aligned(16))) float As[BM * LD];
-    __shared__ __attribute__((aligned(16))) float Bs[BN * LD];
+    __shared__ __attribute__((aligned(16))) unsigned short As[3][BM * LDH];      // planes h, m, l
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[3][BN * LDH];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave - wm * WGN;
@@ -387,18 +426,26 @@ __global__ __launch_bounds__(256, 2) void gemm_rowk(AG ag, const float *__restri
         if (NB > 2) rb2 = *reinterpret_cast<const float4 *>(brow0 + (long)64 * ldb + bko);                 \
         if (NB > 2) rb3 = *reinterpret_cast<const float4 *>(brow0 + (long)96 * ldb + bko);                 \
     }
+#define GRL_STORE_PLANES(S_, o_, v4_)                                                                      \
+    {                                                                                                      \
+        uint2 h_, m_, l_;                                                                                  \
+        split4((v4_).x, (v4_).y, (v4_).z, (v4_).w, h_, m_, l_);                                            \
+        *reinterpret_cast<uint2 *>(&S_[0][o_]) = h_;                                                       \
+        *reinterpret_cast<uint2 *>(&S_[1][o_]) = m_;                                                       \
+        *reinterpret_cast<uint2 *>(&S_[2][o_]) = l_;                                                       \
+    }
 #define GRL_STORE_TILE()                                                                                   \
     {                                                                                                      \
         _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                   \
             const bool v = (vmask >> i) & 1u;                                                              \
             float4 t4 = ra[i];                                                                             \
             t4.x = v ? t4.x : 0.f; t4.y = v ? t4.y : 0.f; t4.z = v ? t4.z : 0.f; t4.w = v ? t4.w : 0.f;    \
-            *reinterpret_cast<float4 *>(As + (trow + 32 * i) * LD + tk4) = t4;                             \
+            GRL_STORE_PLANES(As, (trow + 32 * i) * LDH + tk4, t4)                                          \
         }                                                                                                  \
-        *reinterpret_cast<float4 *>(Bs + trow * LD + tk4) = rb0;                                           \
-        if (NB > 1) *reinterpret_cast<float4 *>(Bs + (trow + 32) * LD + tk4) = rb1;                        \
-        if (NB > 2) *reinterpret_cast<float4 *>(Bs + (trow + 64) * LD + tk4) = rb2;                        \
-        if (NB > 2) *reinterpret_cast<float4 *>(Bs + (trow + 96) * LD + tk4) = rb3;                        \
+        GRL_STORE_PLANES(Bs, trow * LDH + tk4, rb0)                                                        \
+        if (NB > 1) GRL_STORE_PLANES(Bs, (trow + 32) * LDH + tk4, rb1)                                     \
+        if (NB > 2) GRL_STORE_PLANES(Bs, (trow + 64) * LDH + tk4, rb2)                                     \
+        if (NB > 2) GRL_STORE_PLANES(Bs, (trow + 96) * LDH + tk4, rb3)                                     \
     }
 
     f32x16 acc[TM][TN];
@@ -414,9 +461,10 @@ __global__ __launch_bounds__(256, 2) void gemm_rowk(AG ag, const float *__restri
     int kt = 0;
     while (kt < nk && !ag.tile_ok(m0, kt * BK)) ++kt;
     GRL_LOAD_TILE(kt < nk ? kt : 0)
+    // MFMA operand: lane (r = lane & 31, h = lane >> 5) holds k = 8h .. 8h+7 of row r -> one ds_read_b128 per plane
     const int lr = lane & 31, lk = lane >> 5;
-    const float *ap = As + (wm * WM + lr) * LD + lk * 16;
-    const float *bp = Bs + (wn * WN + lr) * LD + lk * 16;
+    const int aro = (wm * WM + lr) * LDH + lk * 8;
+    const int bro = (wn * WN + lr) * LDH + lk * 8;
     while (kt < nk) {
         GRL_STORE_TILE()
         __syncthreads();
@@ -426,25 +474,24 @@ __global__ __launch_bounds__(256, 2) void gemm_rowk(AG ag, const float *__restri
             const int ktl = ktn < nk ? ktn : kt;
             GRL_LOAD_TILE(ktl)
         }
-        __builtin_amdgcn_sched_barrier(0);   // keep every global load above the MFMA phase
+        GRL_SCHED_FENCE
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float4 af[TM], bf[TN];
-#pragma unroll
-            for (int a = 0; a < TM; ++a) af[a] = *reinterpret_cast<const float4 *>(ap + a * 32 * LD + q * 4);
-#pragma unroll
-            for (int b = 0; b < TN; ++b) bf[b] = *reinterpret_cast<const float4 *>(bp + b * 32 * LD + q * 4);
+        for (int s = 0; s < BK / 16; ++s) {
+            bf16x8 af[TM][3], bf[TN][3];
 #pragma unroll
             for (int a = 0; a < TM; ++a)
 #pragma unroll
-                for (int b = 0; b < TN; ++b) {
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].x, bf[b].x, acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].y, bf[b].y, acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].z, bf[b].z, acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].w, bf[b].w, acc[a][b], 0, 0, 0);
-                }
+                for (int p = 0; p < 3; ++p) af[a][p] = *reinterpret_cast<const bf16x8 *>(&As[p][aro + a * 32 * LDH + s * 16]);
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) bf[b][p] = *reinterpret_cast<const bf16x8 *>(&Bs[p][bro + b * 32 * LDH + s * 16]);
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) mfma_x6(acc[a][b], af[a], bf[b]);
         }
-        __builtin_amdgcn_sched_barrier(0);   // ... and the LDS stores of the next tile below it
+        GRL_SCHED_FENCE
         __syncthreads();
         kt = ktn;
     }
@@ -461,23 +508,27 @@ __global__ __launch_bounds__(256, 2) void gemm_rowk(AG ag, const float *__restri
             }
 #undef GRL_LOAD_TILE
 #undef GRL_STORE_TILE
+#undef GRL_STORE_PLANES
 }
 
 // ---------------------------------------------------------------------------- C[I,J] = A^T * B over rows m
 // A element (m, i) = gathered patch element i of row m (same descriptors as above, i plays the role
 // of k); B = dY[m][J] dense.  Block (bi, bj, chunk) reduces rows [chunk*mc, (chunk+1)*mc) and writes
 // its partial tile to slab[chunk][I][J]; a follow-up kernel sums the slabs in a fixed order
-// (deterministic, unlike float atomics).  Tiles are [32][rows] ("KRow"): fragment reads are
-// consecutive floats across lanes, conflict free.
+// (deterministic, unlike float atomics).
+// The reduction index m is the ROW of both operands in memory, the MFMA wants it contiguous per lane: a thread loads
+// NA consecutive rows of the same four columns and writes each column's NA values (packed bf16) to the transposed LDS
+// tile [column][m].  Column 4*c4 + j sits in LDS row j*(BM/4) + c4, which spreads a store's lanes over the banks; the
+// epilogue undoes the permutation.
 template <int BM, int BN, int WGM, int WGN, class AG>
-__global__ __launch_bounds__(256) void gemm_tn(AG ag, const float *__restrict__ dY, int J, int mc, float *__restrict__ slab) {
-    constexpr int BK = 32;
+__global__ __launch_bounds__(256, 2) void gemm_tn(AG ag, const float *__restrict__ dY, int J, int mc, float *__restrict__ slab) {
+    constexpr int BK = 32, LDH = kLdh;
     constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
     constexpr int A4 = BM / 4, B4 = BN / 4;           // float4 per reduction row
     constexpr int NA = BK * A4 / 256, NB = BK * B4 / 256;
-    static_assert(WGM * WGN == 4 && NA >= 1 && NB >= 1, "tile too small");
-    __shared__ __attribute__((aligned(16))) float As[BK * BM];
-    __shared__ __attribute__((aligned(16))) float Bs[BK * BN];
+    static_assert(WGM * WGN == 4 && NA >= 1 && NB >= 1 && NA <= 4 && NB <= 4, "tile size");
+    __shared__ __attribute__((aligned(16))) unsigned short As[3][BM * LDH];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[3][BN * LDH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave - wm * WGN;
     const int i0 = blockIdx.x * BM, j0 = blockIdx.y * BN;
@@ -488,6 +539,9 @@ __global__ __launch_bounds__(256) void gemm_tn(AG ag, const float *__restrict__ 
     int toff, ty, tx;
     ag.tap(i0, toff, ty, tx);   // the BM-wide column run lies inside one tap row (checked on the host)
 
+    // this thread's part of a tile: rows NA*(tid/A4) .. +NA-1 (A), NB*(tid/B4) .. +NB-1 (B), columns 4*ca .. 4*ca+3 / 4*cb ..
+    const int ca = tid % A4, ma = NA * (tid / A4);
+    const int cb = tid % B4, mb = NB * (tid / B4);
     float4 ra[NA], rb[NB];
     unsigned vma = 0, vmb = 0;
     // physical rows of the tile about to be loaded (-1: past the range / padding).  They are fetched one tile ahead of
@@ -496,30 +550,47 @@ __global__ __launch_bounds__(256) void gemm_tn(AG ag, const float *__restrict__ 
 #define GRL_LOAD_IDX(mt_)                                                                                          \
     {                                                                                                              \
         _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                           \
-            const int m = (mt_) + (tid + 256 * i) / A4;                                                            \
+            const int m = (mt_) + ma + i;                                                                          \
             ia[i] = m < mend ? ag.rowidx(m) : -1;                                                                  \
         }                                                                                                          \
         _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                           \
-            const int m = (mt_) + (tid + 256 * i) / B4;                                                            \
+            const int m = (mt_) + mb + i;                                                                          \
             ib[i] = m < mend ? ag.rowidx(m) : -1;                                                                  \
         }                                                                                                          \
     }
 #define GRL_LOAD_TILE()                                                                                            \
     {                                                                                                              \
         _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                           \
-            const int c4 = (tid + 256 * i) % A4;                                                                   \
             const bool inr = ia[i] >= 0;                                                                           \
             long off; int iy0, ix0;                                                                                \
             ag.rowp(inr ? ia[i] : 0, off, iy0, ix0);                                                               \
             const bool v = inr && ag.ok(iy0, ix0, ty, tx);                                                         \
-            ra[i] = *reinterpret_cast<const float4 *>(ag.base + (v ? off + toff : 0L) + c4 * 4);                   \
+            ra[i] = *reinterpret_cast<const float4 *>(ag.base + (v ? off + toff : 0L) + ca * 4);                   \
             vma = v ? (vma | (1u << i)) : (vma & ~(1u << i));                                                      \
         }                                                                                                          \
         _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                           \
-            const int c4 = (tid + 256 * i) % B4;                                                                   \
             const bool v = ib[i] >= 0;                                                                             \
-            rb[i] = *reinterpret_cast<const float4 *>(dY + (long)(v ? ib[i] : 0) * J + j0 + c4 * 4);               \
+            rb[i] = *reinterpret_cast<const float4 *>(dY + (long)(v ? ib[i] : 0) * J + j0 + cb * 4);               \
             vmb = v ? (vmb | (1u << i)) : (vmb & ~(1u << i));                                                      \
+        }                                                                                                          \
+    }
+    // one column's NV consecutive-m values -> NV packed bf16 per plane at S[p][o_]
+#define GRL_STORE_RUN(S_, NV_, o_, r_, comp_)                                                                      \
+    {                                                                                                              \
+        unsigned h_[4], m_[4], l_[4];                                                                              \
+        _Pragma("unroll") for (int i = 0; i < NV_; ++i) split1(r_[i].comp_, h_[i], m_[i], l_[i]);                  \
+        if (NV_ == 4) {                                                                                            \
+            *reinterpret_cast<uint2 *>(&S_[0][o_]) = make_uint2(pack2(h_[0], h_[1]), pack2(h_[2], h_[3]));         \
+            *reinterpret_cast<uint2 *>(&S_[1][o_]) = make_uint2(pack2(m_[0], m_[1]), pack2(m_[2], m_[3]));         \
+            *reinterpret_cast<uint2 *>(&S_[2][o_]) = make_uint2(pack2(l_[0], l_[1]), pack2(l_[2], l_[3]));         \
+        } else if (NV_ == 2) {                                                                                     \
+            *reinterpret_cast<unsigned *>(&S_[0][o_]) = pack2(h_[0], h_[1]);                                       \
+            *reinterpret_cast<unsigned *>(&S_[1][o_]) = pack2(m_[0], m_[1]);                                       \
+            *reinterpret_cast<unsigned *>(&S_[2][o_]) = pack2(l_[0], l_[1]);                                       \
+        } else {                                                                                                   \
+            S_[0][o_] = (unsigned short)(h_[0] >> 16);                                                             \
+            S_[1][o_] = (unsigned short)(m_[0] >> 16);                                                             \
+            S_[2][o_] = (unsigned short)(l_[0] >> 16);                                                             \
         }                                                                                                          \
     }
 #define GRL_STORE_TILE()                                                                                           \
@@ -529,14 +600,22 @@ __global__ __launch_bounds__(256) void gemm_tn(AG ag, const float *__restrict__ 
             float4 t4 = ra[i];                                                                                     \
             t4.x = v ? t4.x : 0.f; t4.y = v ? t4.y : 0.f; t4.z = v ? t4.z : 0.f; t4.w = v ? t4.w : 0.f;            \
             if (AG::kRelu) { t4.x = fmaxf(t4.x, 0.f); t4.y = fmaxf(t4.y, 0.f); t4.z = fmaxf(t4.z, 0.f); t4.w = fmaxf(t4.w, 0.f); } \
-            *reinterpret_cast<float4 *>(As + (tid + 256 * i) * 4) = t4;                                            \
+            ra[i] = t4;                                                                                            \
         }                                                                                                          \
+        GRL_STORE_RUN(As, NA, (0 * A4 + ca) * LDH + ma, ra, x)                                                     \
+        GRL_STORE_RUN(As, NA, (1 * A4 + ca) * LDH + ma, ra, y)                                                     \
+        GRL_STORE_RUN(As, NA, (2 * A4 + ca) * LDH + ma, ra, z)                                                     \
+        GRL_STORE_RUN(As, NA, (3 * A4 + ca) * LDH + ma, ra, w)                                                     \
         _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                           \
             const bool v = (vmb >> i) & 1u;                                                                        \
             float4 t4 = rb[i];                                                                                     \
             t4.x = v ? t4.x : 0.f; t4.y = v ? t4.y : 0.f; t4.z = v ? t4.z : 0.f; t4.w = v ? t4.w : 0.f;            \
-            *reinterpret_cast<float4 *>(Bs + (tid + 256 * i) * 4) = t4;                                            \
+            rb[i] = t4;                                                                                            \
         }                                                                                                          \
+        GRL_STORE_RUN(Bs, NB, (0 * B4 + cb) * LDH + mb, rb, x)                                                     \
+        GRL_STORE_RUN(Bs, NB, (1 * B4 + cb) * LDH + mb, rb, y)                                                     \
+        GRL_STORE_RUN(Bs, NB, (2 * B4 + cb) * LDH + mb, rb, z)                                                     \
+        GRL_STORE_RUN(Bs, NB, (3 * B4 + cb) * LDH + mb, rb, w)                                                     \
     }
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -546,6 +625,8 @@ __global__ __launch_bounds__(256) void gemm_tn(AG ag, const float *__restrict__ 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     const int lr = lane & 31, lk = lane >> 5;
+    const int aro = (wm * WM + lr) * LDH + lk * 8;
+    const int bro = (wn * WN + lr) * LDH + lk * 8;
     if (mbeg < mend) {
         GRL_LOAD_IDX(mbeg)
         GRL_LOAD_TILE()
@@ -555,20 +636,24 @@ __global__ __launch_bounds__(256) void gemm_tn(AG ag, const float *__restrict__ 
             __syncthreads();
             GRL_LOAD_TILE()                  // rows mt + BK .. (row 0, masked, past the end of the range)
             GRL_LOAD_IDX(mt + 2 * BK)
-            __builtin_amdgcn_sched_barrier(0);
+            GRL_SCHED_FENCE
 #pragma unroll
-            for (int kk = 0; kk < BK; kk += 2) {
-                float af[TM], bf[TN];
-#pragma unroll
-                for (int a = 0; a < TM; ++a) af[a] = As[(kk + lk) * BM + wm * WM + a * 32 + lr];
-#pragma unroll
-                for (int b = 0; b < TN; ++b) bf[b] = Bs[(kk + lk) * BN + wn * WN + b * 32 + lr];
+            for (int s = 0; s < BK / 16; ++s) {
+                bf16x8 af[TM][3], bf[TN][3];
 #pragma unroll
                 for (int a = 0; a < TM; ++a)
 #pragma unroll
-                    for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
+                    for (int p = 0; p < 3; ++p) af[a][p] = *reinterpret_cast<const bf16x8 *>(&As[p][aro + a * 32 * LDH + s * 16]);
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) bf[b][p] = *reinterpret_cast<const bf16x8 *>(&Bs[p][bro + b * 32 * LDH + s * 16]);
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) mfma_x6(acc[a][b], af[a], bf[b]);
             }
-            __builtin_amdgcn_sched_barrier(0);
+            GRL_SCHED_FENCE
             __syncthreads();
         }
     }
@@ -579,13 +664,16 @@ __global__ __launch_bounds__(256) void gemm_tn(AG ag, const float *__restrict__ 
         for (int b = 0; b < TN; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                int row = i0 + wm * WM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                int col = j0 + wn * WN + b * 32 + lr;
+                const int pa = wm * WM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;      // LDS rows -> tile columns
+                const int pb = wn * WN + b * 32 + lr;
+                const int row = i0 + 4 * (pa % A4) + pa / A4;
+                const int col = j0 + 4 * (pb % B4) + pb / B4;
                 if (row < I && col < J) out[(long)row * J + col] = acc[a][b][r];
             }
 #undef GRL_LOAD_TILE
 #undef GRL_LOAD_IDX
 #undef GRL_STORE_TILE
+#undef GRL_STORE_RUN
 }
 
 // dst[i] (+)= sum_c slab[c][i]   (fixed association: 4 strided partial sums, then a fixed tree -> bitwise
