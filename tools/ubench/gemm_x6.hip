@@ -39,11 +39,17 @@ __global__ __launch_bounds__(256, 2) void rowk_x6(const float *__restrict__ A, c
     const int trow = tid >> 3, tk4 = (tid & 7) * 4;
     const float *arow = A + (long)(m0 + trow) * K + tk4;
     const float *brow = Bt + (long)(n0 + trow) * K + tk4;
-    float4 ra[NA], rb[NB];
+    float4 ra[NA], rb[NB], ra2[NA], rb2[NB];
 #pragma unroll
     for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const float4 *>(arow + (long)32 * i * K);
 #pragma unroll
     for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const float4 *>(brow + (long)32 * i * K);
+    if (MODE & 8) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) ra2[i] = *reinterpret_cast<const float4 *>(arow + (long)32 * i * K + BK);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) rb2[i] = *reinterpret_cast<const float4 *>(brow + (long)32 * i * K + BK);
+    }
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int a = 0; a < TM; ++a)
@@ -76,7 +82,13 @@ __global__ __launch_bounds__(256, 2) void rowk_x6(const float *__restrict__ A, c
             *reinterpret_cast<uint2 *>(&Bs[2][o]) = l;
         }
         __syncthreads();
-        const int ktn = kt + 1 < nk ? kt + 1 : kt;
+        const int ktn = (MODE & 8) ? (kt + 2 < nk ? kt + 2 : kt) : (kt + 1 < nk ? kt + 1 : kt);
+        if (MODE & 8) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) { ra[i] = ra2[i]; ra2[i] = *reinterpret_cast<const float4 *>(arow + (long)32 * i * K + ktn * BK); }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) { rb[i] = rb2[i]; rb2[i] = *reinterpret_cast<const float4 *>(brow + (long)32 * i * K + ktn * BK); }
+        } else
         if (!(MODE & 1)) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const float4 *>(arow + (long)32 * i * K + ktn * BK);
@@ -108,6 +120,110 @@ __global__ __launch_bounds__(256, 2) void rowk_x6(const float *__restrict__ A, c
                 }
         }
         if (!(MODE & 4)) __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int row = m0 + wm * WM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                int col = n0 + wn * WN + b * 32 + lr;
+                if (row < M && col < N) C[(long)row * N + col] = acc[a][b][r];
+            }
+}
+
+
+// software-pipelined variant: LDS double-buffered, ONE workgroup per CU; while the MFMAs consume tile kt from buffer kt&1
+// the same wave splits tile kt+1 (already in registers) into buffer (kt+1)&1 and tile kt+2 is in flight from global memory.
+#define SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+template <int BM, int BN, int WGM, int WGN, int MODE = 0>
+__global__ __launch_bounds__(256, 1) void rowk_x6p(const float *__restrict__ A, const float *__restrict__ Bt, float *__restrict__ C, int M, int N, int K) {
+    constexpr int BK = 32, LDH = 40;
+    constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32, NA = BM / 32, NB = BN / 32;
+    constexpr int ASZ = BM * LDH, BSZ = BN * LDH;
+    __shared__ __attribute__((aligned(16))) unsigned short As[2][3][ASZ];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[2][3][BSZ];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave - wm * WGN;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int trow = tid >> 3, tk4 = (tid & 7) * 4;
+    const float *arow = A + (long)(m0 + trow) * K + tk4;
+    const float *brow = Bt + (long)(n0 + trow) * K + tk4;
+    float4 ra0[NA], rb0[NB], ra1[NA], rb1[NB];
+    const int nk = K / BK;
+#define LOADSET(RA, RB, kt_)                                                                                                  \
+    {                                                                                                                         \
+        const int kk = (kt_) < nk ? (kt_) : nk - 1;                                                                           \
+        _Pragma("unroll") for (int i = 0; i < NA; ++i) RA[i] = *reinterpret_cast<const float4 *>(arow + (long)32 * i * K + kk * BK); \
+        _Pragma("unroll") for (int i = 0; i < NB; ++i) RB[i] = *reinterpret_cast<const float4 *>(brow + (long)32 * i * K + kk * BK); \
+    }
+#define SPLITSET(RA, RB, buf_)                                                                                                \
+    {                                                                                                                         \
+        _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                                      \
+            uint2 h, m, l;                                                                                                    \
+            split4(RA[i], h, m, l);                                                                                           \
+            const int o = (trow + 32 * i) * LDH + tk4;                                                                        \
+            *reinterpret_cast<uint2 *>(&As[buf_][0][o]) = h;                                                                  \
+            *reinterpret_cast<uint2 *>(&As[buf_][1][o]) = m;                                                                  \
+            *reinterpret_cast<uint2 *>(&As[buf_][2][o]) = l;                                                                  \
+        }                                                                                                                     \
+        _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                                      \
+            uint2 h, m, l;                                                                                                    \
+            split4(RB[i], h, m, l);                                                                                           \
+            const int o = (trow + 32 * i) * LDH + tk4;                                                                        \
+            *reinterpret_cast<uint2 *>(&Bs[buf_][0][o]) = h;                                                                  \
+            *reinterpret_cast<uint2 *>(&Bs[buf_][1][o]) = m;                                                                  \
+            *reinterpret_cast<uint2 *>(&Bs[buf_][2][o]) = l;                                                                  \
+        }                                                                                                                     \
+    }
+#define MFMASET(buf_)                                                                                                         \
+    _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                                           \
+        bf16x8 af[TM][3], bf[TN][3];                                                                                          \
+        _Pragma("unroll") for (int a = 0; a < TM; ++a)                                                                        \
+            _Pragma("unroll") for (int p = 0; p < 3; ++p) af[a][p] = *reinterpret_cast<const bf16x8 *>(&As[buf_][p][aro + a * 32 * LDH + s * 16]); \
+        _Pragma("unroll") for (int b = 0; b < TN; ++b)                                                                        \
+            _Pragma("unroll") for (int p = 0; p < 3; ++p) bf[b][p] = *reinterpret_cast<const bf16x8 *>(&Bs[buf_][p][bro + b * 32 * LDH + s * 16]); \
+        _Pragma("unroll") for (int a = 0; a < TM; ++a)                                                                        \
+            _Pragma("unroll") for (int b = 0; b < TN; ++b) {                                                                  \
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][2], bf[b][0], acc[a][b], 0, 0, 0);                  \
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bf[b][2], acc[a][b], 0, 0, 0);                  \
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][1], bf[b][1], acc[a][b], 0, 0, 0);                  \
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][1], bf[b][0], acc[a][b], 0, 0, 0);                  \
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bf[b][1], acc[a][b], 0, 0, 0);                  \
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][0], bf[b][0], acc[a][b], 0, 0, 0);                  \
+            }                                                                                                                 \
+    }
+#define HINTS()                                                                                                               \
+    if (MODE & 1) {                                                                                                           \
+        _Pragma("unroll") for (int g = 0; g < 24; ++g) {                                                                      \
+            SGB(0x008, 1); SGB(0x100, 1); SGB(0x002, 4); SGB(0x008, 1); SGB(0x200, 1); SGB(0x002, 4);                         \
+        }                                                                                                                     \
+    }
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const int lr = lane & 31, lk = lane >> 5;
+    const int aro = (wm * WM + lr) * LDH + lk * 8, bro = (wn * WN + lr) * LDH + lk * 8;
+    LOADSET(ra0, rb0, 0)
+    LOADSET(ra1, rb1, 1)
+    SPLITSET(ra0, rb0, 0)
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {      // nk even
+        LOADSET(ra0, rb0, kt + 2)
+        MFMASET(0)
+        SPLITSET(ra1, rb1, 1)
+        HINTS()
+        __syncthreads();
+        LOADSET(ra1, rb1, kt + 3)
+        MFMASET(1)
+        SPLITSET(ra0, rb0, 0)
+        HINTS()
         __syncthreads();
     }
 #pragma unroll
@@ -269,9 +385,19 @@ static void run(int M, int N, int K) {
         case 2: ms = time_ms([&] { hipLaunchKernelGGL((rowk_x6<128, 128, 2, 2, 2>), g, dim3(256), 0, 0, A, B, C, M, N, K); }, 5); break;
         case 3: ms = time_ms([&] { hipLaunchKernelGGL((rowk_x6<128, 128, 2, 2, 3>), g, dim3(256), 0, 0, A, B, C, M, N, K); }, 5); break;
         case 4: ms = time_ms([&] { hipLaunchKernelGGL((rowk_x6<128, 128, 2, 2, 4>), g, dim3(256), 0, 0, A, B, C, M, N, K); }, 5); break;
+        case 5: ms = time_ms([&] { hipLaunchKernelGGL((rowk_x6<128, 128, 2, 2, 8>), g, dim3(256), 0, 0, A, B, C, M, N, K); }, 5); break;
+        case 6: ms = time_ms([&] { hipLaunchKernelGGL((rowk_x6<128, 128, 2, 2, 12>), g, dim3(256), 0, 0, A, B, C, M, N, K); }, 5); break;
         default: continue;
         }
-        printf("   mode %d (1: no global loads, 2: no split, 4: no sched barriers): %8.3f ms %7.1f TF\n", mode, ms, flops / ms / 1e9);
+        printf("   mode %d (1: no global loads, 2: no split, 4: no sched barriers; mode 5 = 2-deep prefetch, 6 = 2-deep + no fences): %8.3f ms %7.1f TF\n", mode, ms, flops / ms / 1e9);
+    }
+    for (int v = 0; v < 2; ++v) {
+        dim3 g(N / 128, M / 128);
+        float ms = v == 0 ? time_ms([&] { hipLaunchKernelGGL((rowk_x6p<128, 128, 2, 2, 0>), g, dim3(256), 0, 0, A, B, C, M, N, K); }, 5)
+                          : time_ms([&] { hipLaunchKernelGGL((rowk_x6p<128, 128, 2, 2, 1>), g, dim3(256), 0, 0, A, B, C, M, N, K); }, 5);
+        (void)hipMemcpy(hC.data(), C, hC.size() * 4, hipMemcpyDeviceToHost);
+        double rms, w = err_vs_double(hA, hB, hC, M, N, K, &rms);
+        printf("M %6d N %4d K %4d  x6 pipelined%s 128x128: %8.3f ms %7.1f TF  err/sum|ab| worst %.3g rms %.3g\n", M, N, K, v ? " +hints" : "       ", ms, flops / ms / 1e9, w, rms);
     }
     {
         dim3 g(N / 64, M / 256);
