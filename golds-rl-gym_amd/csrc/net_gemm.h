@@ -382,9 +382,20 @@ __global__ __launch_bounds__(256, 2) void gemm_rowk(AG ag, const float *__restri
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave - wm * WGN;
-    // N tiles vary fastest in launch order: the workgroups that share one A tile run together, so it is
-    // fetched from HBM once and served to the others by L2 (the B operand is small and always cached)
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    // Workgroups are dealt round-robin to the 8 XCDs in launch order (x fastest), each with its own L2: left alone, the
+    // N tiles that share one A tile land on different XCDs and every one of them fetches it again.  Inside each run of
+    // 8 M-tiles the order is therefore transposed: XCD x takes M-tile 8g + x with ALL its N tiles (inactive trailing
+    // M tiles stay spread over the XCDs).  A last partial run keeps the launch order.
+    int bx = blockIdx.x, by = blockIdx.y;
+    {
+        const int nx = gridDim.x, L = by * nx + bx, g = L / (8 * nx);
+        if ((g + 1) * 8 <= (int)gridDim.y) {
+            const int l = L - g * 8 * nx;
+            by = g * 8 + (l & 7);
+            bx = l >> 3;
+        }
+    }
+    const int m0 = by * BM, n0 = bx * BN;
     if (!ag.tile_active(m0)) return;     // block-uniform (padding tiles of the group-sorted layouts)
     const int M = ag.rows, K = ag.K();
     const int trow = tid >> 3, tk4 = (tid & 7) * 4;
@@ -531,10 +542,21 @@ __global__ __launch_bounds__(256, 2) void gemm_tn(AG ag, const float *__restrict
     __shared__ __attribute__((aligned(16))) unsigned short Bs[3][BN * LDH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave - wm * WGN;
-    const int i0 = blockIdx.x * BM, j0 = blockIdx.y * BN;
+    // all tiles of one row range (grid z) on one XCD, so its L2 serves the re-reads of the same rows (see gemm_rowk)
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    {
+        const int nx = gridDim.x, T = nx * gridDim.y, L = bz * T + by * nx + bx, g = L / (8 * T);
+        if ((g + 1) * 8 <= (int)gridDim.z) {
+            const int l = L - g * 8 * T, t = l >> 3;
+            bz = g * 8 + (l & 7);
+            by = t / nx;
+            bx = t - by * nx;
+        }
+    }
+    const int i0 = bx * BM, j0 = by * BN;
     const int I = ag.K();
     int mbeg, mend;
-    ag.mrange(blockIdx.z, mc, mbeg, mend);
+    ag.mrange(bz, mc, mbeg, mend);
 
     int toff, ty, tx;
     ag.tap(i0, toff, ty, tx);   // the BM-wide column run lies inside one tap row (checked on the host)
@@ -657,7 +679,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn(AG ag, const float *__restrict
             __syncthreads();
         }
     }
-    float *out = slab + (long)blockIdx.z * I * J;
+    float *out = slab + (long)bz * I * J;
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll

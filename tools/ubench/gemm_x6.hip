@@ -350,12 +350,12 @@ static float time_ms(F launch, int reps) {
     return ms / reps;
 }
 
-static void run(int M, int N, int K) {
+static void run(int M, int N, int K, float scale = 1.f) {
     std::vector<float> hA((long)M * K), hB((long)N * K), hC((long)M * N);
     unsigned s = 12345u;
     auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 32768.0f - 1.0f; };
-    for (auto &v : hA) v = rnd() * (1.f + 0.37f * rnd());
-    for (auto &v : hB) v = 0.05f * rnd() * (1.f + 0.11f * rnd());
+    for (auto &v : hA) v = scale * rnd() * (1.f + 0.37f * rnd());
+    for (auto &v : hB) v = scale * 0.05f * rnd() * (1.f + 0.11f * rnd());
     float *A, *B, *C;
     (void)hipMalloc(&A, hA.size() * 4);
     (void)hipMalloc(&B, hB.size() * 4);
@@ -412,7 +412,8 @@ static void run(int M, int N, int K) {
 }
 
 int main() {
-    run(40960, 512, 1600);     // dense1 patch forward
-    run(409600, 256, 256);     // head layers
+    run(40960, 512, 1600);     // dense1 patch forward: 1280 workgroups = 2.5 rounds of 512
+    run(65536, 512, 1600);     // 2048 workgroups = 4 full rounds
+    run(65536, 512, 1600, 0.f);     // same on zeros (no operand toggling: clock / power effect)
     return 0;
 }
