@@ -370,7 +370,7 @@ __device__ __forceinline__ void mfma_x6(f32x16 &acc, const bf16x8 (&a)[3], const
 constexpr int kLdh = 40;       // bf16 per LDS tile row: 32 + 8 pad (80 B) -> the 16 lanes of every ds_read_b128 group hit 16 distinct 4-bank slots
 
 // ---------------------------------------------------------------------------- C = A(rowk) * Bt^T
-template <int BM, int BN, int WGM, int WGN, class AG, class Epi>
+template <int BM, int BN, int WGM, int WGN, class AG, class Epi, bool XCD_ORDER = true>
 __global__ __launch_bounds__(256, 2) void gemm_rowk(AG ag, const float *__restrict__ Bt, int ldb, int N, Epi epi) {
     constexpr int BK = 32, LDH = kLdh;
     constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
@@ -385,9 +385,10 @@ __global__ __launch_bounds__(256, 2) void gemm_rowk(AG ag, const float *__restri
     // Workgroups are dealt round-robin to the 8 XCDs in launch order (x fastest), each with its own L2: left alone, the
     // N tiles that share one A tile land on different XCDs and every one of them fetches it again.  Inside each run of
     // 8 M-tiles the order is therefore transposed: XCD x takes M-tile 8g + x with ALL its N tiles (inactive trailing
-    // M tiles stay spread over the XCDs).  A last partial run keeps the launch order.
+    // M tiles stay spread over the XCDs).  A last partial run keeps the launch order.  XCD_ORDER = false keeps the launch
+    // order everywhere (measured per launch: the wide-N data gradient of the dense1 patch is faster spread out).
     int bx = blockIdx.x, by = blockIdx.y;
-    {
+    if (XCD_ORDER) {
         const int nx = gridDim.x, L = by * nx + bx, g = L / (8 * nx);
         if ((g + 1) * 8 <= (int)gridDim.y) {
             const int l = L - g * 8 * nx;
@@ -531,7 +532,7 @@ __global__ __launch_bounds__(256, 2) void gemm_rowk(AG ag, const float *__restri
 // NA consecutive rows of the same four columns and writes each column's NA values (packed bf16) to the transposed LDS
 // tile [column][m].  Column 4*c4 + j sits in LDS row j*(BM/4) + c4, which spreads a store's lanes over the banks; the
 // epilogue undoes the permutation.
-template <int BM, int BN, int WGM, int WGN, class AG>
+template <int BM, int BN, int WGM, int WGN, class AG, bool XCD_ORDER = true>
 __global__ __launch_bounds__(256, 2) void gemm_tn(AG ag, const float *__restrict__ dY, int J, int mc, float *__restrict__ slab) {
     constexpr int BK = 32, LDH = kLdh;
     constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
@@ -544,7 +545,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn(AG ag, const float *__restrict
     const int wm = wave / WGN, wn = wave - wm * WGN;
     // all tiles of one row range (grid z) on one XCD, so its L2 serves the re-reads of the same rows (see gemm_rowk)
     int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-    {
+    if (XCD_ORDER) {
         const int nx = gridDim.x, T = nx * gridDim.y, L = bz * T + by * nx + bx, g = L / (8 * T);
         if ((g + 1) * 8 <= (int)gridDim.z) {
             const int l = L - g * 8 * T, t = l >> 3;
