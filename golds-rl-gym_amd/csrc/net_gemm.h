@@ -1,4 +1,4 @@
-// fp32 MFMA GEMM building blocks for the policy/value nets (gfx950 only).
+// fp32 GEMM building blocks for the policy/value nets on the gfx950 matrix cores.
 //
 // All dense contractions of ConvSingleAgentPolicyNetwork (reference
 // fed_gym/agents/paac/policy_v_network.py:14-59) -- conv2, conv3 as implicit GEMMs over NHWC
@@ -9,16 +9,19 @@
 //        data gradient: Bt = W itself (dX = dY * W^T), or a rearranged kernel for the transposed convs
 //   gemm_tn<BM,BN,WGM,WGN>     C[I,J] = sum_m A[m,I] * B[m,J]   (weight gradient, split over m into slabs)
 //
-// built on v_mfma_f32_32x32x2_f32 (exact f32, 64 FLOP/clk/SIMD = the fp32 peak of 157 TF; the
-// reference computes in float32, so no reduced-precision MFMA is used).  256 threads = 4 waves,
-// BK = 32, operands staged through LDS with register prefetch of the next K-tile so the global
-// loads fly under the 64-cycle MFMAs.
+// Arithmetic.  The reference computes in float32, and so do these kernels -- but on the bf16 matrix pipe, which on
+// CDNA4 runs 16x the rate of v_mfma_f32_32x32x2_f32 (2.5 PFLOP/s against 157 TFLOP/s).  While a tile is staged into
+// LDS every fp32 operand x is split EXACTLY into three bf16 numbers x = h + m + l (8 + 8 + 8 significand bits by
+// truncation: h = upper half of x, m = upper half of x - h, l = x - h - m; nothing is rounded away).  A product
+// a * b is then nine bf16 x bf16 terms, each exact in fp32; the six of weight >= 2^-24 |a||b| (hh, hm, mh, mm, hl, lh)
+// are accumulated in fp32 by v_mfma_f32_32x32x16_bf16, the three of weight <= 2^-24 (ml, lm, ll: below one fp32 ulp of
+// the product) are dropped.  Six bf16 MFMAs per K = 16 step replace eight fp32 ones: 2.7x the matrix-pipe rate, and the
+// error against a double-precision reference is the same as the fp32 MFMA loop's (tools/ubench/gemm_x6.hip: rms error
+// relative to sum|a||b| 2.0-2.1e-8 against 2.4e-8 on the dense1 / dense2 / head shapes).
 //
-// gemm_rowk LDS layout: both tiles are [rows][36] floats.  The MFMA's k index is a free
-// permutation as long as A and B agree, so lane half lk = lane>>5 owns k in [16*lk, 16*lk+16) and
-// fetches four consecutive k per ds_read_b128 (row stride 36 floats = 144 B puts the 16 lanes of
-// every b128 service group on 16 distinct 4-bank slots: conflict free).  4x fewer LDS instructions
-// than one ds_read_b32 per k.
+// 256 threads = 4 waves, BK = 32, register prefetch of the next K-tile so the global loads fly under the MFMAs.  LDS
+// holds three bf16 planes per operand, rows of 32 + 8 bf16 (80 B): an MFMA fragment (8 consecutive k of one row) is one
+// ds_read_b128 per plane and the 16 lanes of every b128 service group land on 16 distinct 4-bank slots (conflict free).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

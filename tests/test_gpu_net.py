@@ -1,4 +1,4 @@
-"""GPU parity of ConvSingleAgentPolicyNetwork (HIP, fp32 MFMA) against the float64 numpy restatement
+"""GPU parity of ConvSingleAgentPolicyNetwork (HIP, fp32 on the matrix cores) against the float64 numpy restatement
 oracle/nets.py with shared weights.  Network numerics are 'parity unpinned' wrt TensorFlow (absent);
 tolerance: float32 forward within 2e-5 relative of the float64 oracle, gradients within 1e-4."""
 import numpy as np
@@ -447,3 +447,27 @@ def test_split_gradient_step_equals_fused_and_supports_host_exchange():
         assert np.array_equal(p[6144:], outs[0][0][6144:])
         np.testing.assert_allclose(p[:6144], outs[0][0][:6144], rtol=1e-5, atol=1e-8)
         np.testing.assert_allclose(list(st.values()), list(outs[0][1].values()), rtol=1e-6)
+
+
+def test_forward_error_is_at_the_float32_level():
+    """The GEMMs run fp32 operands as three exact bf16 terms with six of the nine partial products (net_gemm.h): the
+    result must be as close to the float64 oracle as a plain float32 evaluation of the same net (numpy/BLAS float32)."""
+    E = 6
+    eng, net, p, states, obs = _setup(E)
+    out = net.predict()
+    mu, sigma, vs, c = NN.conv_forward(p, states, 1000.0, keep=True)
+    p32 = {k: v.astype(np.float32) for k, v in p.items()}
+    mu32, sigma32, vs32, c32 = NN.conv_forward(p32, states.astype(np.float32), np.float32(1000.0), keep=True)
+    assert c32["d1"].dtype == np.float32
+    report = {}
+    for name in ("a2", "a3", "d1", "d2", "p1", "v1", "v2"):
+        ref = c[name][40:]
+        got = net.read_activation(name, ref.shape).astype(np.float64)
+        scale = np.abs(ref).max()
+        e_gpu = np.abs(got - ref).max() / scale
+        e_f32 = np.abs(c32[name][40:].astype(np.float64) - ref).max() / scale
+        report[name] = (e_gpu, e_f32)
+        assert e_gpu <= 3.0 * e_f32 + 2e-7, (name, e_gpu, e_f32)
+    e_mu = np.abs(out["mu"] - mu).max()
+    assert e_mu <= 3.0 * np.abs(mu32.astype(np.float64) - mu).max() + 2e-7, report
+    print("max error / max|ref|  (device, numpy float32):", {k: ("%.2e" % a, "%.2e" % b) for k, (a, b) in report.items()})
