@@ -83,6 +83,18 @@ static bool field_info(grl_handle *h, int32_t f, FieldInfo &fi) {
             default: return false;
         }
     }
+    if (kind == GRL_ENV_TICKER) {
+        switch (f) {
+            case GRL_FLD_TICKER_CASH: fi = {h->tk.cash, 8, 1, false}; return true;
+            case GRL_FLD_TICKER_ASSETS: fi = {h->tk.assets, 8, 1, false}; return true;
+            case GRL_FLD_TICKER_QUANTITY: fi = {h->tk.q, 8, 2, false}; return true;
+            case GRL_FLD_TICKER_IDX: fi = {h->tk.idx, 4, 1, false}; return true;
+            case GRL_FLD_TICKER_START: fi = {h->tk.start, 4, 1, false}; return true;
+            case GRL_FLD_TICKER_START0: fi = {h->tk.start0, 4, 1, false}; return true;
+            case GRL_FLD_NHIST: fi = {h->tk.nhist, 4, 1, false}; return true;
+            default: return false;
+        }
+    }
     return false;
 }
 
@@ -90,6 +102,7 @@ static int action_cols(const grl_handle *h) {
     switch (h->cfg.env_kind) {
         case GRL_ENV_SWARM: return N_AGENTS * 2;
         case GRL_ENV_SOLOW: return 1;
+        case GRL_ENV_TICKER: return 4;
         default: return h->cfg.n_assets;
     }
 }
@@ -98,6 +111,7 @@ static int reset_list(grl_handle *h, const int32_t *list_dev, const int32_t *cou
     switch (h->cfg.env_kind) {
         case GRL_ENV_SWARM: return swarm_launch_reset(h, list_dev, count_dev, max_count);
         case GRL_ENV_SOLOW: return solow_launch_reset(h, list_dev, count_dev, max_count, true);
+        case GRL_ENV_TICKER: return ticker_launch_reset(h, list_dev, count_dev, max_count);
         default: return trade_launch_reset(h, list_dev, count_dev, max_count);
     }
 }
@@ -111,12 +125,13 @@ extern "C" {
 int grl_abi_version(void) { return GRL_ABI_VERSION; }
 
 int grl_config_default(int32_t env_kind, grl_config *cfg) {
-    if (!cfg || env_kind < 0 || env_kind > 2) return GRL_E_INVALID;
+    if (!cfg || env_kind < 0 || env_kind > GRL_ENV_TICKER) return GRL_E_INVALID;
     memset(cfg, 0, sizeof(*cfg));
     cfg->struct_size = (int32_t)sizeof(grl_config);
     cfg->env_kind = env_kind;
     cfg->num_envs = 32;                                   // -ec default (train_paac_conv.py:109)
     cfg->max_episode_steps = env_kind == GRL_ENV_SWARM ? 128 : 1024;   // fed_gym/__init__.py:3-33
+    if (env_kind == GRL_ENV_TICKER) cfg->max_episode_steps = 1023;     // not registered in the reference: last row of the 1024-row window
     cfg->grid_size = 84;                                  // --height (train_paac_conv.py:114)
     cfg->n_assets = 2;                                    // fed_env.py:269
     cfg->solow_p = 1; cfg->solow_q = 1;                   // fed_env.py:166
@@ -132,7 +147,11 @@ int grl_create(const grl_config *cfg, grl_handle **out) {
     if (!cfg || !out) return fail(nullptr, GRL_E_INVALID, "grl_create: null argument");
     *out = nullptr;
     if (cfg->struct_size != (int32_t)sizeof(grl_config)) return fail(nullptr, GRL_E_INVALID, "grl_create: grl_config size mismatch (ABI drift)");
-    if (cfg->env_kind < 0 || cfg->env_kind > 2) return fail(nullptr, GRL_E_INVALID, "grl_create: unknown env_kind");
+    if (cfg->env_kind < 0 || cfg->env_kind > GRL_ENV_TICKER) return fail(nullptr, GRL_E_INVALID, "grl_create: unknown env_kind");
+    if (cfg->env_kind == GRL_ENV_TICKER && (cfg->n_assets != 2 || cfg->rnn_length < 1 || cfg->rnn_length > 32))
+        return fail(nullptr, GRL_E_INVALID, "grl_create: the Ticker table has two price columns (n_assets must be 2) and rnn_length must be in 1..32");
+    if (cfg->env_kind == GRL_ENV_TICKER && (cfg->max_episode_steps < 0 || cfg->max_episode_steps > 1023))
+        return fail(nullptr, GRL_E_INVALID, "grl_create: Ticker episodes live inside a 1024-row window: max_episode_steps must be in 0..1023 (0: no cap, stepping past the window is an error as in the reference)");
     if (cfg->num_envs <= 0) return fail(nullptr, GRL_E_INVALID, "grl_create: num_envs must be positive");
     if (cfg->env_kind == GRL_ENV_SWARM && (cfg->grid_size < 2 || cfg->grid_size > 254)) return fail(nullptr, GRL_E_INVALID, "grl_create: grid_size must be in 2..254");
     if (cfg->env_kind == GRL_ENV_TRADE && (cfg->n_assets < 1 || cfg->n_assets > 64)) return fail(nullptr, GRL_E_INVALID, "grl_create: n_assets must be in 1..64");
@@ -161,7 +180,7 @@ int grl_create(const grl_config *cfg, grl_handle **out) {
     h->step_in_flight = false;
     h->prof_on = false; h->prof_used = 0;
     h->stream = nullptr; h->ev0 = nullptr; h->ev1 = nullptr;
-    h->sw = {}; h->so = {}; h->tr = {};
+    h->sw = {}; h->so = {}; h->tr = {}; h->tk = {};
     int rc = GRL_OK;
     auto bail = [&](int code) {
         g_create_error = h->err;
@@ -186,6 +205,7 @@ int grl_create(const grl_config *cfg, grl_handle **out) {
     switch (cfg->env_kind) {
         case GRL_ENV_SWARM: rc = swarm_alloc(h); break;
         case GRL_ENV_SOLOW: rc = solow_alloc(h); break;
+        case GRL_ENV_TICKER: rc = ticker_alloc(h); break;
         default: rc = trade_alloc(h); break;
     }
     if (rc) return bail(rc);
@@ -243,6 +263,13 @@ int grl_swarm_reset_injected(grl_handle *h, const double *x0, const double *xa0,
     return swarm_reset_injected(h, x0, xa0, random_actions, agent_noise, particle_noise);
 }
 
+int grl_ticker_set_table(grl_handle *h, const double *rows, int32_t nrows) {
+    if (!h || h->cfg.env_kind != GRL_ENV_TICKER) return fail(h, GRL_E_INVALID, "grl_ticker_set_table: not a Ticker handle");
+    if (!rows) return fail(h, GRL_E_INVALID, "grl_ticker_set_table: null argument");
+    hipSetDevice(h->cfg.device_id);
+    return ticker_set_table(h, rows, nrows);
+}
+
 static int copy_field(grl_handle *h, int32_t field, void *host, size_t bytes, bool to_device) {
     if (!h || !host) return fail(h, GRL_E_INVALID, "grl_set/get_state: null argument");
     hipSetDevice(h->cfg.device_id);
@@ -281,6 +308,7 @@ int grl_step_device(grl_handle *h, const float *actions_dev) {
     switch (h->cfg.env_kind) {
         case GRL_ENV_SWARM: rc = swarm_launch_step(h, actions_dev); break;
         case GRL_ENV_SOLOW: rc = solow_launch_step(h, actions_dev); break;
+        case GRL_ENV_TICKER: rc = ticker_launch_step(h, actions_dev); break;
         default: rc = trade_launch_step(h, actions_dev); break;
     }
     if (rc == GRL_OK) h->step_in_flight = true;
@@ -305,6 +333,10 @@ int grl_wait(grl_handle *h) {
         GRL_HIP(h, hipMemcpy(&flag, h->err_flag, 4, hipMemcpyDeviceToHost));
         if (flag) {
             GRL_HIP(h, hipMemset(h->err_flag, 0, 4));
+            if (h->cfg.env_kind == GRL_ENV_TICKER) {
+                if (flag & 0xFFFF) return fail(h, GRL_E_ACTION_RANGE, std::to_string(flag & 0xFFFF) + " env(s) received a choice other than 0 (hold), 1 (buy), 2 (sell)");
+                return fail(h, GRL_E_STATE, std::to_string(flag >> 16) + " env(s) stepped past row 1023 of their price window (reference: IndexError, fed_env.py:133)");
+            }
             if (h->cfg.env_kind == GRL_ENV_TRADE)
                 return fail(h, GRL_E_ACTION_RANGE, std::to_string(flag) + " env(s) received an action outside Box(-1, 1)");
             return fail(h, GRL_E_STATE, std::to_string(flag) + " env(s) popped from an empty shock tape (no TimeLimit and more than T steps)");
@@ -322,6 +354,8 @@ int grl_outputs(grl_handle *h, grl_out_ptrs *o) {
         o->reward_f64 = h->sw.reward64; o->locust_bins = h->sw.lbins; o->agent_bins = h->sw.abins; o->positions = h->sw.pos;
     } else if (h->cfg.env_kind == GRL_ENV_SOLOW) {
         o->obs_raw = h->so.obs_raw; o->obs = h->so.obs; o->history = h->so.history;
+    } else if (h->cfg.env_kind == GRL_ENV_TICKER) {
+        o->obs_raw = h->tk.obs_raw; o->obs = h->tk.obs; o->reward_f64 = h->tk.reward64;
     } else {
         o->obs_raw = h->tr.obs_raw; o->obs = h->tr.obs;
     }
@@ -333,7 +367,7 @@ int grl_read_output(grl_handle *h, const char *which, void *host, size_t bytes) 
     hipSetDevice(h->cfg.device_id);
     grl_out_ptrs o;
     grl_outputs(h, &o);
-    size_t E = h->E, S = h->cfg.env_kind == GRL_ENV_SOLOW ? 2 : (size_t)(1 + 2 * h->cfg.n_assets);
+    size_t E = h->E, S = h->cfg.env_kind == GRL_ENV_SOLOW ? 2 : (h->cfg.env_kind == GRL_ENV_TICKER ? 7 : (size_t)(1 + 2 * h->cfg.n_assets));
     const void *src = nullptr;
     size_t need = 0;
     std::string w(which);
@@ -364,6 +398,7 @@ int grl_observe(grl_handle *h) {
     switch (h->cfg.env_kind) {
         case GRL_ENV_SWARM: rc = swarm_launch_observe(h); break;
         case GRL_ENV_SOLOW: rc = solow_launch_observe(h); break;
+        case GRL_ENV_TICKER: rc = ticker_launch_observe(h); break;
         default: rc = trade_launch_observe(h); break;
     }
     if (rc) return rc;
@@ -392,7 +427,7 @@ int grl_swarm_materialize_states(grl_handle *h, int32_t first, int32_t count, fl
 int grl_transform_actions_device(grl_handle *h, float *actions_dev, int32_t rows) {
     if (!h || !actions_dev || rows < 0) return fail(h, GRL_E_INVALID, "grl_transform_actions_device: bad argument");
     hipSetDevice(h->cfg.device_id);
-    int cols = h->cfg.env_kind == GRL_ENV_SWARM ? 2 : (h->cfg.env_kind == GRL_ENV_SOLOW ? 1 : h->cfg.n_assets);
+    int cols = h->cfg.env_kind == GRL_ENV_SWARM ? 2 : action_cols(h);
     if (rows == 0) return GRL_OK;
     return launch_transform(h, h->cfg.env_kind, actions_dev, rows, cols);
 }
@@ -401,7 +436,7 @@ int grl_transform_actions_host(grl_handle *h, const float *in, float *out, int32
     if (!h || !in || !out || rows < 0) return fail(h, GRL_E_INVALID, "grl_transform_actions_host: bad argument");
     if (rows == 0) return GRL_OK;
     hipSetDevice(h->cfg.device_id);
-    int cols = h->cfg.env_kind == GRL_ENV_SWARM ? 2 : (h->cfg.env_kind == GRL_ENV_SOLOW ? 1 : h->cfg.n_assets);
+    int cols = h->cfg.env_kind == GRL_ENV_SWARM ? 2 : action_cols(h);
     size_t bytes = (size_t)rows * cols * 4;
     float *d = nullptr;
     GRL_HIP(h, hipMalloc((void **)&d, bytes));

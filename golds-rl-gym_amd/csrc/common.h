@@ -19,7 +19,7 @@ constexpr int SWARM_TPB = SWARM_EPB * N_LOCUSTS;
 // generator stream ids (ctr[3]); the CPU restatement is oracle/oracle.py:rng_block
 enum : uint32_t {
     RS_SWARM_X0 = 0, RS_SWARM_XA0 = 1, RS_SWARM_RANDACT = 2, RS_SWARM_ANOISE = 3, RS_SWARM_PNOISE = 4,
-    RS_SOLOW_Z0 = 8, RS_SOLOW_TAPE = 9, RS_TRADE_PRICE = 12, RS_USER = 64
+    RS_SOLOW_Z0 = 8, RS_SOLOW_TAPE = 9, RS_TRADE_PRICE = 12, RS_TICKER_START = 16, RS_USER = 64
 };
 
 struct SwarmState {
@@ -47,6 +47,16 @@ struct TradeState {
     float std_e;
 };
 
+struct TickerState {
+    double *cash, *assets, *q;        // q (E,2)
+    double *reward64;
+    int32_t *idx, *start, *start0;    // row inside the window, first row of the window, start restored under SNAPSHOT
+    int32_t *nhist;
+    float *obs_raw, *obs;             // (E,7)
+    const double *table;              // (rows,4) on the device: price, inverse price, volume, volume
+    int rows;
+};
+
 }  // namespace grl
 
 struct grl_handle {
@@ -67,6 +77,7 @@ struct grl_handle {
     grl::SwarmState sw;
     grl::SolowState so;
     grl::TradeState tr;
+    grl::TickerState tk;
     std::vector<void *> allocs;   // everything hipMalloc'ed by the handle
     std::vector<void *> user_allocs;
     // per-kernel profiling (grl_profile_*)
@@ -104,6 +115,12 @@ int trade_alloc(grl_handle *h);
 int trade_launch_step(grl_handle *h, const float *actions_dev);
 int trade_launch_reset(grl_handle *h, const int32_t *list_dev, const int32_t *count_dev, int max_count);
 int trade_launch_observe(grl_handle *h);
+// ticker.hip
+int ticker_alloc(grl_handle *h);
+int ticker_set_table(grl_handle *h, const double *rows_host, int nrows);
+int ticker_launch_step(grl_handle *h, const float *actions_dev);
+int ticker_launch_reset(grl_handle *h, const int32_t *list_dev, const int32_t *count_dev, int max_count);
+int ticker_launch_observe(grl_handle *h);
 // rollout_math.hip
 int launch_returns(grl_handle *h, const float *r, const float *v, const float *mask, const float *boot, int T, int B,
                    float gamma, float lam, float scale, float clip_lo, float clip_hi, float *y, float *adv);

@@ -70,7 +70,10 @@ __global__ void transform_kernel(int kind, float *a, int rows, int cols) {
     } else {
         if (i >= rows * cols) return;
         float x = a[i];
-        if (kind == GRL_ENV_SOLOW) {
+        if (kind == GRL_ENV_SOLOW || kind == GRL_ENV_TICKER) {
+            // Ticker rows are [choice0, choice1, fraction0, fraction1]: the choices pass, the fractions get the sigmoid
+            // (TickerGatedTraderWorker.transform_raw_action, a3c/worker.py:491-494)
+            if (kind == GRL_ENV_TICKER && (i & 3) < 2) return;
             float z = expf(-fabsf(x));
             a[i] = x >= 0.f ? 1.0f / (1.0f + z) : z / (1.0f + z);
         } else {

@@ -8,7 +8,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libgoldsrl.so")
 
-ENV_SWARM, ENV_SOLOW, ENV_TRADE = 0, 1, 2
+ENV_SWARM, ENV_SOLOW, ENV_TRADE, ENV_TICKER = 0, 1, 2, 3
 F_RESEED_EACH_RESET, F_RESET_FROM_SNAPSHOT, F_INJECT_NOISE, F_SWARM_FAST_MATH, F_SWARM_NO_OBSERVE = 1, 2, 4, 8, 16
 
 OK, E_INVALID, E_NO_DEVICE, E_HIP, E_SIZE, E_ACTION_RANGE, E_STATE, E_COMM = 0, -1, -2, -3, -4, -5, -6, -7
@@ -18,6 +18,7 @@ FLD = dict(
     SWARM_X=0, SWARM_XA=1, SWARM_PNOISE=2, SWARM_ANOISE=3, RESET_X=4, RESET_XA=5, RESET_PNOISE=6, RESET_ANOISE=7,
     ELAPSED=8, EPISODE=9, SOLOW_K=16, SOLOW_Z=17, SOLOW_E=18, SOLOW_TAPE=19, SOLOW_TAPE_POS=20, SOLOW_Z0=21, NHIST=22,
     TRADE_CASH=32, TRADE_ASSETS=33, TRADE_QUANTITY=34, TRADE_PRICES=35, TRADE_NORMALS=36,
+    TICKER_CASH=48, TICKER_ASSETS=49, TICKER_QUANTITY=50, TICKER_IDX=51, TICKER_START=52, TICKER_START0=53,
 )
 
 
@@ -55,6 +56,7 @@ SIGNATURES = {
     "grl_last_error": (C.c_char_p, [_P]),
     "grl_reset": (C.c_int, [_P, _P, _I]),
     "grl_swarm_reset_injected": (C.c_int, [_P, _P, _P, _P, _P, _P]),
+    "grl_ticker_set_table": (C.c_int, [_P, _P, C.c_int32]),
     "grl_set_state": (C.c_int, [_P, _I, _P, _SZ]),
     "grl_get_state": (C.c_int, [_P, _I, _P, _SZ]),
     "grl_step_async": (C.c_int, [_P, _P]),
@@ -110,9 +112,9 @@ def _ptr(a):
 
 _FIELD_DTYPE = {}
 for _k, _v in FLD.items():
-    if _k.startswith("SWARM_") or _k.startswith("RESET_"):
+    if _k.startswith("SWARM_") or _k.startswith("RESET_") or _k in ("TICKER_CASH", "TICKER_ASSETS", "TICKER_QUANTITY"):
         _FIELD_DTYPE[_v] = np.float64
-    elif _k in ("ELAPSED", "EPISODE", "SOLOW_TAPE_POS", "NHIST"):
+    elif _k in ("ELAPSED", "EPISODE", "SOLOW_TAPE_POS", "NHIST", "TICKER_IDX", "TICKER_START", "TICKER_START0"):
         _FIELD_DTYPE[_v] = np.int32
     else:
         _FIELD_DTYPE[_v] = np.float32
@@ -143,6 +145,8 @@ class Engine(object):
             self.action_shape, self.obs_dim = (self.E, 10, 2), None
         elif env_kind == ENV_SOLOW:
             self.action_shape, self.obs_dim = (self.E, 1), 2
+        elif env_kind == ENV_TICKER:
+            self.action_shape, self.obs_dim = (self.E, 4), 7       # [choice0, choice1, fraction0, fraction1]
         else:
             self.action_shape, self.obs_dim = (self.E, cfg.n_assets), 1 + 2 * cfg.n_assets
 
@@ -167,7 +171,8 @@ class Engine(object):
         f = FLD[field] if isinstance(field, str) else field
         inner = {0: (80, 2), 1: (10, 2), 2: (80, 2), 3: (10, 2), 4: (80, 2), 5: (10, 2), 6: (80, 2), 7: (10, 2),
                  8: (), 9: (), 16: (), 17: (c.solow_p,), 18: (max(c.solow_q, 1),), 19: (c.solow_tape_len,), 20: (),
-                 21: (c.solow_p,), 22: (), 32: (), 33: (), 34: (c.n_assets,), 35: (c.n_assets,), 36: (c.n_assets,)}[f]
+                 21: (c.solow_p,), 22: (), 32: (), 33: (), 34: (c.n_assets,), 35: (c.n_assets,), 36: (c.n_assets,),
+                 48: (), 49: (), 50: (2,), 51: (), 52: (), 53: ()}[f]
         return (E,) + inner
 
     # -- state
@@ -186,6 +191,13 @@ class Engine(object):
             if a.shape != w:
                 raise ValueError("swarm_reset_injected: expected shape %s, got %s" % (w, a.shape))
         self._check(self.lib.grl_swarm_reset_injected(self.h, *[_ptr(a) for a in arrs]))
+
+    def ticker_set_table(self, matrix):
+        """Upload the OpenCloseSampler data matrix (rows, 4) every env samples its 1024-row windows from."""
+        m = np.ascontiguousarray(matrix, dtype=np.float64)
+        if m.ndim != 2 or m.shape[1] != 4:
+            raise ValueError("ticker_set_table: expected a (rows, 4) matrix, got %s" % (m.shape,))
+        self._check(self.lib.grl_ticker_set_table(self.h, _ptr(m), m.shape[0]))
 
     def set_state(self, field, value):
         f = FLD[field] if isinstance(field, str) else field
@@ -259,7 +271,7 @@ class Engine(object):
     # -- transforms / returns
     def transform_actions(self, actions):
         a = np.ascontiguousarray(actions, dtype=np.float32)
-        cols = 2 if self.kind == ENV_SWARM else (1 if self.kind == ENV_SOLOW else self.cfg.n_assets)
+        cols = 2 if self.kind == ENV_SWARM else (1 if self.kind == ENV_SOLOW else (4 if self.kind == ENV_TICKER else self.cfg.n_assets))
         flat = a.reshape(-1, cols)
         out = np.empty_like(flat)
         self._check(self.lib.grl_transform_actions_host(self.h, _ptr(flat), _ptr(out), flat.shape[0]))

@@ -55,3 +55,21 @@ class SolowStateProcessor(StateProcessor):
         if len(history) == 1:
             return np.array(history[0]).reshape((1, -1))
         return np.array(history)
+
+
+class TickerTraderStateProcessor(StateProcessor):
+    """state_processors.py:45-66.  The device env already emits this vector as its `obs` output (csrc/ticker.hip,
+    float32); this host form serves single states handed over by the gym-style TickerEnv."""
+
+    def __init__(self, n_assets):
+        super(TickerTraderStateProcessor, self).__init__(None)
+        self.n_assets = n_assets
+
+    def process_state(self, raw_state):
+        raw = np.asarray(raw_state, dtype=np.float64)
+        n = self.n_assets
+        cash, held, prices, volumes = raw[0], raw[1:1 + n], raw[1 + n:1 + 2 * n], raw[1 + 2 * n:]
+        return np.concatenate([[np.log(cash + 1e-4)], np.log(held + 1), np.log(prices), volumes])
+
+    def process_temporal_states(self, history):
+        return np.vstack(history)[:, 1 + self.n_assets:]

@@ -1,7 +1,7 @@
 """gym-style registry for the device-backed envs.  Ids, entry points, episode caps and kwargs are
 those of the reference's registrations (fed_gym/__init__.py:3-33, fed_gym/envs/fed_env.py:10-27);
 `make` applies gym 0.9.4's TimeLimit semantics through the engine's `max_episode_steps`."""
-from .fed_env import SolowEnv, TradeAR1Env, register_solow_env, registry  # noqa: F401
+from .fed_env import SolowEnv, TickerEnv, TradeAR1Env, register_solow_env, registry  # noqa: F401
 from .multiagent import SwarmEnv  # noqa: F401
 
 registry.update({

@@ -74,3 +74,49 @@ class TradeAR1Env(object):
 
     def seed(self, seed=None):
         return []
+
+
+class TickerEnv(object):
+    """Two-asset account trading an asset and its mirror along a historical price table with a bid/ask spread
+    (fed_env.py:89-158).  action = [choices, fractions]: choices[i] in {0 hold, BUY_IDX, SELL_IDX}, fractions[i] the share
+    of cash to spend (buys are rescaled to sum to at most 1) or of the position to sell.  The account lives on the
+    device in float64; the env samples its 1024-row window there."""
+    BUY_IDX = 1
+    SELL_IDX = 2
+
+    def __init__(self, starting_balance=10., inverse_asset=True, n_assets=2, sampler=None, ticker='IEF', max_episode_steps=None,
+                 device_id=0, seed=1692, window_start=None):
+        if starting_balance != 10. or n_assets != 2:
+            raise NotImplementedError("only the reference defaults starting_balance=10, n_assets=2 are supported")
+        from .data.sampler import OpenCloseSampler
+        self.MIN_CASH = 1.
+        self.n_assets = n_assets
+        self.spread = 0.006
+        self.data = sampler if sampler is not None else OpenCloseSampler(ticker=ticker, inverse_asset=inverse_asset)
+        flags = 0 if window_start is None else _ffi.F_RESET_FROM_SNAPSHOT
+        self._eng = _ffi.Engine(_ffi.ENV_TICKER, 1, device_id=device_id, seed=int(seed), flags=flags,
+                                max_episode_steps=int(1023 if max_episode_steps is None else max_episode_steps))
+        self._eng.ticker_set_table(self.data.data_matrix)
+        if window_start is not None:
+            self._eng.set_state("TICKER_START0", np.array([window_start], dtype=np.int32))
+
+    def reset(self):
+        self._eng.reset()
+        return self._eng.read("obs_raw")[0].astype(np.float64)
+
+    def step(self, action):
+        choices = np.asarray(action[0]).reshape(self.n_assets)
+        fractions = np.asarray(action[1], dtype=np.float64).reshape(self.n_assets)
+        a = np.concatenate([choices.astype(np.float32), fractions.astype(np.float32)]).reshape(1, 4)
+        self._eng.step_async(a)
+        try:
+            self._eng.wait()
+        except _ffi.GrlError as e:
+            if e.code == _ffi.E_STATE:
+                raise IndexError("index 1024 is out of bounds for axis 0 with size 1024")       # price_vol_data[data_idx]
+            raise
+        obs = self._eng.read("obs_raw")[0].astype(np.float64)
+        return obs, float(self._eng.read("reward_f64")[0]), bool(self._eng.read("done")[0]), {}
+
+    def seed(self, seed=None):
+        return []

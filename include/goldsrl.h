@@ -47,6 +47,12 @@ extern "C" {
 #define GRL_ENV_SWARM 0 /* Swarm-v0 / Swarm-eval-v0   (envs/multiagent.py) */
 #define GRL_ENV_SOLOW 1 /* Solow-v0 / Solow-p-q-*-v0  (envs/fed_env.py:161-250) */
 #define GRL_ENV_TRADE 2 /* TradeAR1-v0                (envs/fed_env.py:268-334) */
+#define GRL_ENV_TICKER 3 /* TickerEnv over an OpenCloseSampler table (envs/fed_env.py:89-158, envs/data/sampler.py:8-41);
+                          * needs grl_ticker_set_table before the first reset.  Actions (E,4) f32: choice0, choice1
+                          * (0 hold, 1 BUY_IDX, 2 SELL_IDX), fraction0, fraction1.  Observation (E,7):
+                          * [cash, q0, q1, p0, p1, v0, v1]; `obs` is TickerTraderStateProcessor.process_state of it
+                          * (agents/state_processors.py:50-63).  The reference registers no TimeLimit for this env and
+                          * raises IndexError at row 1024 of its window: grl_config_default sets max_episode_steps = 1023 */
 
 /* ---- config flags ------------------------------------------------------------------- */
 /* Reset reproduces the same episode every time, as an env built with seed=<n> does because
@@ -115,7 +121,14 @@ enum grl_field {
     GRL_FLD_TRADE_ASSETS = 33,  /* f32 (E,) */
     GRL_FLD_TRADE_QUANTITY = 34,/* f32 (E,n) */
     GRL_FLD_TRADE_PRICES = 35,  /* f32 (E,n) */
-    GRL_FLD_TRADE_NORMALS = 36  /* f32 (E,n) N(0,1) draws for the NEXT step (GRL_F_INJECT_NOISE) */
+    GRL_FLD_TRADE_NORMALS = 36, /* f32 (E,n) N(0,1) draws for the NEXT step (GRL_F_INJECT_NOISE) */
+    /* Ticker (account in float64 like the reference's numpy scalars) */
+    GRL_FLD_TICKER_CASH = 48,     /* f64 (E,)   cash_balance */
+    GRL_FLD_TICKER_ASSETS = 49,   /* f64 (E,)   equity at the last step's prices (the reward's old_assets) */
+    GRL_FLD_TICKER_QUANTITY = 50, /* f64 (E,2)  positions */
+    GRL_FLD_TICKER_IDX = 51,      /* i32 (E,)   data_idx: row inside the env's 1024-row window */
+    GRL_FLD_TICKER_START = 52,    /* i32 (E,)   first table row of the window in use (sampler.py:38 start_idx) */
+    GRL_FLD_TICKER_START0 = 53    /* i32 (E,)   start restored by every reset under GRL_F_RESET_FROM_SNAPSHOT */
 };
 
 /* ---- step outputs: DEVICE pointers, valid from grl_wait() until grl_destroy() ----------
@@ -152,6 +165,11 @@ int grl_reset(grl_handle *h, const int32_t *env_idx, int32_t n);
 int grl_swarm_reset_injected(grl_handle *h, const double *x0, const double *xa0, const double *random_actions,
                              const double *agent_noise, const double *particle_noise);
 
+/* Ticker: uploads the price table every env samples its 1024-row windows from -- the `data_matrix` of
+ * OpenCloseSampler (envs/data/sampler.py:11-28): rows (nrows,4) f64 C-order = [price, inverse price, volume, volume],
+ * nrows >= 1024, prices > 0.  Replaces TickerEnv.__init__'s `self.data = sampler.OpenCloseSampler(...)`
+ * (envs/fed_env.py:107).  Must be called before the first grl_reset. */
+int grl_ticker_set_table(grl_handle *h, const double *rows, int32_t nrows);
 int grl_set_state(grl_handle *h, int32_t field, const void *host, size_t bytes);
 int grl_get_state(grl_handle *h, int32_t field, void *host, size_t bytes);
 
