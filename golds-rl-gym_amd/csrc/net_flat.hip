@@ -277,8 +277,10 @@ static int enqueue_rollout(grl_fnet *net, int T) {
                : launch_forward(net, E, obs, nullptr, net->mu, net->sigma, net->ro_boot, false, h->tr.nhist);
     if (rc) return rc;
     // rewards clipped to [-2, 2] (paac.py:145), masked n-step return (paac.py:167-172), adv / scale (paac.py:177)
-    if ((rc = launch_returns(h, net->ro_rew, net->ro_val, net->ro_mask, net->ro_boot, T, E, net->cfg.gamma, 1.0f, net->cfg.scale, -2.f, 2.f,
-                             net->ro_y, net->ro_adv)))
+    // gae_lambda < 1: the A3C worker's GAE on the raw rewards (a3c/worker.py:232-294)
+    const bool gae = net->cfg.gae_lambda < 1.0f;
+    if ((rc = launch_returns(h, net->ro_rew, net->ro_val, net->ro_mask, net->ro_boot, T, E, net->cfg.gamma, gae ? net->cfg.gae_lambda : 1.0f,
+                             net->cfg.scale, gae ? 0.f : -2.f, gae ? 0.f : 2.f, net->ro_y, net->ro_adv)))
         return ffail(net, rc, h->err);
     return GRL_OK;
 }
@@ -295,7 +297,7 @@ int grl_fnet_config_default(grl_fnet_config *cfg) {
     cfg->struct_size = (int32_t)sizeof(grl_fnet_config);
     cfg->static_size = 2; cfg->temporal_size = 2; cfg->rnn_length = 5; cfg->num_actions = 1;     // train_paac_solow.py:96-129
     cfg->rnn_hidden = 32; cfg->static_hidden = 32; cfg->max_samples = 4096 * 20;
-    cfg->scale = 100.f; cfg->clip_norm = 40.f; cfg->gamma = 0.99f; cfg->mu_bound = 5.f;
+    cfg->scale = 100.f; cfg->clip_norm = 40.f; cfg->gamma = 0.99f; cfg->mu_bound = 5.f; cfg->gae_lambda = 1.f;
     return GRL_OK;
 }
 
@@ -307,6 +309,7 @@ int grl_fnet_create(grl_handle *h, const grl_fnet_config *cfg, grl_fnet **out) {
     if (cfg->temporal_size < 1 || cfg->temporal_size > MAXD || cfg->static_size < 1 || cfg->static_size > MAXS0 || cfg->num_actions < 1 ||
         cfg->num_actions > MAXA || cfg->rnn_length < 1 || cfg->rnn_length > 32 || cfg->max_samples < 1)
         return fail(h, GRL_E_INVALID, "grl_fnet_create: size out of range");
+    if (!(cfg->gae_lambda > 0.f && cfg->gae_lambda <= 1.f)) return fail(h, GRL_E_INVALID, "grl_fnet_create: gae_lambda must be in (0, 1]");
     hipSetDevice(h->cfg.device_id);
     grl_fnet *n = new grl_fnet();
     n->h = h; n->cfg = *cfg;

@@ -11,7 +11,7 @@ _P, _I, _F, _SZ = C.c_void_p, C.c_int32, C.c_float, C.c_size_t
 class GrlFnetConfig(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("static_size", C.c_int32), ("temporal_size", C.c_int32), ("rnn_length", C.c_int32),
                 ("num_actions", C.c_int32), ("rnn_hidden", C.c_int32), ("static_hidden", C.c_int32), ("max_samples", C.c_int32),
-                ("scale", C.c_float), ("clip_norm", C.c_float), ("gamma", C.c_float), ("mu_bound", C.c_float)]
+                ("scale", C.c_float), ("clip_norm", C.c_float), ("gamma", C.c_float), ("mu_bound", C.c_float), ("gae_lambda", C.c_float)]
 
 
 FNET_SIGNATURES = {

@@ -67,7 +67,8 @@ class FlatPolicyVNetwork(object):
         clip = self.clip_norm if self.clip_norm_type == 'global' else 0.0
         self.net = _ffi_flat.FlatNet(engine, static_size=self.static_size, temporal_size=self.temporal_size, rnn_length=rnn_length,
                                      num_actions=self.num_actions, scale=self.scale, clip_norm=clip, gamma=gamma,
-                                     max_samples=max_samples or engine.E * 64)
+                                     max_samples=max_samples or engine.E * 64,
+                                     gae_lambda=float(self.conf.get('gae_lambda', 1.0)))     # <1: the A3C worker's GAE targets
         self.net.set_params(_ffi_flat.default_init_flat(seed, static_size=self.static_size, temporal_size=self.temporal_size,
                                                         num_actions=self.num_actions))
         return self

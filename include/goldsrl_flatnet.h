@@ -34,6 +34,10 @@ typedef struct grl_fnet_config {
     float clip_norm;        /* 40, 'global'; <= 0: 'ignore' */
     float gamma;            /* 0.99 */
     float mu_bound;         /* ub = -lb = 5 (policy_v_network.py:207-208) */
+    float gae_lambda;       /* 1: PAAC's clipped, masked n-step return (paac.py:145,159-177).  In (0,1): the A3C worker's
+                             * GAE on the raw rewards (a3c/worker.py:232-294, `_lambda` = 0.96 at :87): delta_t = r_t +
+                             * gamma V_{t+1} - V_t, advantage = discounted sum with gamma*lambda, target = advantage + V_t,
+                             * bootstrap 0 behind a finished episode (done_penalty, :232) */
 } grl_fnet_config;
 
 typedef struct grl_fnet grl_fnet;

@@ -164,3 +164,37 @@ def test_trade_paac_rollout_gru_policy():
     for name, _ in shapes:
         err = np.abs(got[name] - g[name]).max() / (np.abs(g[name]).max() + 1e-12)
         assert err < 3e-4, (name, err)
+
+
+def test_trade_rollout_with_the_a3c_workers_gae():
+    """gae_lambda = 0.96 (a3c/worker.py:87): the rollout's targets follow GaussianWorker.update (a3c/worker.py:232-294) --
+    raw rewards, delta_t = r_t + gamma V_{t+1} - V_t, advantage discounted with gamma*lambda, target = advantage + V_t --
+    applied per episode segment with bootstrap 0 behind a finished episode (done_penalty) and V(s_T) at the end."""
+    from goldsrl import _ffi, _ffi_flat
+    E, T, n, R = 64, 12, 2, 5
+    S = 1 + 2 * n
+    eng = _ffi.Engine(_ffi.ENV_TRADE, E, seed=4, n_assets=n, rnn_length=R, max_episode_steps=5)
+    eng.reset()
+    net = _ffi_flat.FlatNet(eng, static_size=S, temporal_size=S, rnn_length=R, num_actions=n, max_samples=E * T, scale=100.0, gae_lambda=0.96)
+    _params(net, S, S, n)
+    net.rollout(T); eng.wait()
+    vals, rews, masks = (net.read_rollout(k, (T, E)) for k in ("values", "rewards", "masks"))
+    boot, y, adv = net.read_rollout("boot", (E,)), net.read_rollout("y", (T, E)), net.read_rollout("adv", (T, E))
+    assert (masks == 0).sum() == 2 * E                     # TimeLimit(5): two finished episodes inside 12 steps
+    oy, oadv = np.zeros((T, E)), np.zeros((T, E))
+    for b in range(E):
+        ends = [t for t in range(T) if masks[t, b] == 0]
+        t0 = 0
+        for t1 in ends + [T - 1]:
+            seg = slice(t0, t1 + 1)
+            finished = t1 in ends
+            bt = np.zeros(1) if finished else boot[b:b + 1].astype(np.float64)
+            if t0 <= t1:
+                a, tgt = O.gae(rews[seg, b:b + 1].astype(np.float64), vals[seg, b:b + 1].astype(np.float64), bt, 0.99, 0.96)
+                oadv[seg, b], oy[seg, b] = a[:, 0], tgt[:, 0]
+            t0 = t1 + 1
+    np.testing.assert_allclose(y, oy, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(adv, oadv / 100.0, rtol=1e-5, atol=1e-6)
+    assert np.abs(rews).max() > 0 and np.isfinite(net.train_rollout(1e-4)["loss"])
+    with pytest.raises(_ffi.GrlError):
+        _ffi_flat.FlatNet(eng, static_size=S, temporal_size=S, rnn_length=R, num_actions=n, gae_lambda=0.0)
