@@ -14,14 +14,14 @@
 // LDS every fp32 operand x is split EXACTLY into three bf16 numbers x = h + m + l (8 + 8 + 8 significand bits by
 // truncation: h = upper half of x, m = upper half of x - h, l = x - h - m; nothing is rounded away).  A product
 // a * b is then nine bf16 x bf16 terms, each exact in fp32; the six of weight >= 2^-24 |a||b| (hh, hm, mh, mm, hl, lh)
-// are accumulated in fp32 by v_mfma_f32_32x32x16_bf16, the three of weight <= 2^-24 (ml, lm, ll: below one fp32 ulp of
+// are accumulated in fp32 by v_mfma_f32_16x16x32_bf16, the three of weight <= 2^-24 (ml, lm, ll: below one fp32 ulp of
 // the product) are dropped.  Six bf16 MFMAs per K = 16 step replace eight fp32 ones: 2.7x the matrix-pipe rate, and the
 // error against a double-precision reference is the same as the fp32 MFMA loop's (tools/ubench/gemm_x6.hip: rms error
 // relative to sum|a||b| 2.0-2.1e-8 against 2.4e-8 on the dense1 / dense2 / head shapes).
 //
 // 256 threads = 4 waves, BK = 32, register prefetch of the next K-tile so the global loads fly under the MFMAs.  LDS
-// holds three bf16 planes per operand, rows of 32 + 8 bf16 (80 B): an MFMA fragment (8 consecutive k of one row) is one
-// ds_read_b128 per plane and the 16 lanes of every b128 service group land on 16 distinct 4-bank slots (conflict free).
+// holds three bf16 planes per operand in 64-byte rows with an XOR swizzle of the 16-byte chunks (kLdh, swz below): an
+// MFMA fragment (8 consecutive k of one row) is one conflict-free ds_read_b128 per plane.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -29,6 +29,7 @@
 namespace grl {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef GRL_SCHED_FENCE
 #define GRL_SCHED_FENCE __builtin_amdgcn_sched_barrier(0);
@@ -361,22 +362,29 @@ __device__ __forceinline__ void split4(float x0, float x1, float x2, float x3, u
     m = make_uint2(pack2(m0, m1), pack2(m2, m3));
     l = make_uint2(pack2(l0, l1), pack2(l2, l3));
 }
-// acc += a * b with the six partial products of weight >= 2^-24 (smallest first)
-__device__ __forceinline__ void mfma_x6(f32x16 &acc, const bf16x8 (&a)[3], const bf16x8 (&b)[3]) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
+// acc += a * b with the six partial products of weight >= 2^-24 (smallest first), on v_mfma_f32_16x16x32_bf16: per FLOP it
+// draws less power than the 32x32x16 form, and on toggling operands the matrix pipe is power-limited (measured with
+// tools/ubench/gemm_x6.hip: 177-196 against 150-155 TFLOP/s of fp32 work on the dense1 shapes)
+__device__ __forceinline__ void mfma_x6(f32x4 &acc, const bf16x8 (&a)[3], const bf16x8 (&b)[3]) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], acc, 0, 0, 0);
 }
-constexpr int kLdh = 40;       // bf16 per LDS tile row: 32 + 8 pad (80 B) -> the 16 lanes of every ds_read_b128 group hit 16 distinct 4-bank slots
+// LDS tiles: [row][32 bf16] = 64-byte rows, no padding.  The 16-byte chunk c (8 consecutive k) of row r is stored at chunk
+// position c ^ swz(r), swz = {0,2,3,1}[(r >> 2) & 3].  The MFMA operand map (lane l: row l & 15, k = 8 (l >> 4) .. +7) then
+// reads one ds_read_b128 per plane with the 16 lanes of every service group on 16 distinct 4-bank slots, and the staging
+// stores of gemm_rowk (8 lanes per row, 8 bytes each) cover whole rows: both conflict free (checked by enumeration).
+constexpr int kLdh = 32;
+__device__ __forceinline__ int swz(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }
 
 // ---------------------------------------------------------------------------- C = A(rowk) * Bt^T
 template <int BM, int BN, int WGM, int WGN, class AG, class Epi, bool XCD_ORDER = true>
 __global__ __launch_bounds__(256, 2) void gemm_rowk(AG ag, const float *__restrict__ Bt, int ldb, int N, Epi epi) {
     constexpr int BK = 32, LDH = kLdh;
-    constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
+    constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 16, TN = WN / 16;       // 16x16 MFMA tiles per wave
     constexpr int NA = BM / 32;                       // float4 per thread for the A tile
     constexpr int NB = BN / 32;                       // float4 per thread for the B tile
     static_assert(WGM * WGN == 4 && TM >= 1 && TN >= 1, "4 waves");
@@ -403,6 +411,7 @@ __global__ __launch_bounds__(256, 2) void gemm_rowk(AG ag, const float *__restri
     if (!ag.tile_active(m0)) return;     // block-uniform (padding tiles of the group-sorted layouts)
     const int M = ag.rows, K = ag.K();
     const int trow = tid >> 3, tk4 = (tid & 7) * 4;
+    const int wo = (((tk4 >> 3) ^ swz(trow)) << 3) + (tk4 & 4);      // swizzled k offset of this thread's stores (rows trow + 32 i)
 
     // A rows owned by this thread: r = trow + 32*i
     long aoff[NA];
@@ -455,31 +464,32 @@ __global__ __launch_bounds__(256, 2) void gemm_rowk(AG ag, const float *__restri
             const bool v = (vmask >> i) & 1u;                                                              \
             float4 t4 = ra[i];                                                                             \
             t4.x = v ? t4.x : 0.f; t4.y = v ? t4.y : 0.f; t4.z = v ? t4.z : 0.f; t4.w = v ? t4.w : 0.f;    \
-            GRL_STORE_PLANES(As, (trow + 32 * i) * LDH + tk4, t4)                                          \
+            GRL_STORE_PLANES(As, (trow + 32 * i) * LDH + wo, t4)                                           \
         }                                                                                                  \
-        GRL_STORE_PLANES(Bs, trow * LDH + tk4, rb0)                                                        \
-        if (NB > 1) GRL_STORE_PLANES(Bs, (trow + 32) * LDH + tk4, rb1)                                     \
-        if (NB > 2) GRL_STORE_PLANES(Bs, (trow + 64) * LDH + tk4, rb2)                                     \
-        if (NB > 2) GRL_STORE_PLANES(Bs, (trow + 96) * LDH + tk4, rb3)                                     \
+        GRL_STORE_PLANES(Bs, trow * LDH + wo, rb0)                                                         \
+        if (NB > 1) GRL_STORE_PLANES(Bs, (trow + 32) * LDH + wo, rb1)                                      \
+        if (NB > 2) GRL_STORE_PLANES(Bs, (trow + 64) * LDH + wo, rb2)                                      \
+        if (NB > 2) GRL_STORE_PLANES(Bs, (trow + 96) * LDH + wo, rb3)                                      \
     }
 
-    f32x16 acc[TM][TN];
+    f32x4 acc[TM][TN];
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
         for (int b = 0; b < TN; ++b)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+            for (int r = 0; r < 4; ++r) acc[a][b][r] = 0.f;
 
     const int nk = K / BK;
     // K-tiles whose tap is outside the image for the WHOLE workgroup are skipped (tile_ok is block-uniform)
     int kt = 0;
     while (kt < nk && !ag.tile_ok(m0, kt * BK)) ++kt;
     GRL_LOAD_TILE(kt < nk ? kt : 0)
-    // MFMA operand: lane (r = lane & 31, h = lane >> 5) holds k = 8h .. 8h+7 of row r -> one ds_read_b128 per plane
-    const int lr = lane & 31, lk = lane >> 5;
-    const int aro = (wm * WM + lr) * LDH + lk * 8;
-    const int bro = (wn * WN + lr) * LDH + lk * 8;
+    // MFMA operand: lane (r = lane & 15, g = lane >> 4) holds k = 8g .. 8g+7 of row r -> one ds_read_b128 per plane
+    const int l16 = lane & 15, kg = lane >> 4;
+    const int ro = (kg ^ swz(l16)) << 3;
+    const int aro = (wm * WM + l16) * LDH + ro;
+    const int bro = (wn * WN + l16) * LDH + ro;
     while (kt < nk) {
         GRL_STORE_TILE()
         __syncthreads();
@@ -490,35 +500,34 @@ __global__ __launch_bounds__(256, 2) void gemm_rowk(AG ag, const float *__restri
             GRL_LOAD_TILE(ktl)
         }
         GRL_SCHED_FENCE
-#pragma unroll
-        for (int s = 0; s < BK / 16; ++s) {
-            bf16x8 af[TM][3], bf[TN][3];
-#pragma unroll
-            for (int a = 0; a < TM; ++a)
-#pragma unroll
-                for (int p = 0; p < 3; ++p) af[a][p] = *reinterpret_cast<const bf16x8 *>(&As[p][aro + a * 32 * LDH + s * 16]);
+        {   // one K = 32 step per tile
+            bf16x8 bf[TN][3];
 #pragma unroll
             for (int b = 0; b < TN; ++b)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) bf[b][p] = *reinterpret_cast<const bf16x8 *>(&Bs[p][bro + b * 32 * LDH + s * 16]);
+                for (int p = 0; p < 3; ++p) bf[b][p] = *reinterpret_cast<const bf16x8 *>(&Bs[p][bro + b * 16 * LDH]);
 #pragma unroll
-            for (int a = 0; a < TM; ++a)
+            for (int a = 0; a < TM; ++a) {
+                bf16x8 af[3];
 #pragma unroll
-                for (int b = 0; b < TN; ++b) mfma_x6(acc[a][b], af[a], bf[b]);
+                for (int p = 0; p < 3; ++p) af[p] = *reinterpret_cast<const bf16x8 *>(&As[p][aro + a * 16 * LDH]);
+#pragma unroll
+                for (int b = 0; b < TN; ++b) mfma_x6(acc[a][b], af, bf[b]);
+            }
         }
         GRL_SCHED_FENCE
         __syncthreads();
         kt = ktn;
     }
-    // C/D map of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    // C/D map of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + reg
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
         for (int b = 0; b < TN; ++b)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int row = m0 + wm * WM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                int col = n0 + wn * WN + b * 32 + lr;
+            for (int r = 0; r < 4; ++r) {
+                int row = m0 + wm * WM + a * 16 + 4 * kg + r;
+                int col = n0 + wn * WN + b * 16 + l16;
                 if (row < M && col < N) epi(row, col, acc[a][b][r]);
             }
 #undef GRL_LOAD_TILE
@@ -538,7 +547,7 @@ __global__ __launch_bounds__(256, 2) void gemm_rowk(AG ag, const float *__restri
 template <int BM, int BN, int WGM, int WGN, class AG, bool XCD_ORDER = true>
 __global__ __launch_bounds__(256, 2) void gemm_tn(AG ag, const float *__restrict__ dY, int J, int mc, float *__restrict__ slab) {
     constexpr int BK = 32, LDH = kLdh;
-    constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
+    constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 16, TN = WN / 16;
     constexpr int A4 = BM / 4, B4 = BN / 4;           // float4 per reduction row
     constexpr int NA = BK * A4 / 256, NB = BK * B4 / 256;
     static_assert(WGM * WGN == 4 && NA >= 1 && NB >= 1 && NA <= 4 && NB <= 4, "tile size");
@@ -600,6 +609,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn(AG ag, const float *__restrict
             vmb = v ? (vmb | (1u << i)) : (vmb & ~(1u << i));                                                      \
         }                                                                                                          \
     }
+    // tile row rho, reduction position m (0..31) -> swizzled LDS offset
+#define GRL_TN_OFF(rho_, m_) ((rho_) * LDH + ((((m_) >> 3) ^ swz(rho_)) << 3) + ((m_) & 7))
     // one column's NV consecutive-m values -> NV packed bf16 per plane at S[p][o_]
 #define GRL_STORE_RUN(S_, NV_, o_, r_, comp_)                                                                      \
     {                                                                                                              \
@@ -628,31 +639,32 @@ __global__ __launch_bounds__(256, 2) void gemm_tn(AG ag, const float *__restrict
             if (AG::kRelu) { t4.x = fmaxf(t4.x, 0.f); t4.y = fmaxf(t4.y, 0.f); t4.z = fmaxf(t4.z, 0.f); t4.w = fmaxf(t4.w, 0.f); } \
             ra[i] = t4;                                                                                            \
         }                                                                                                          \
-        GRL_STORE_RUN(As, NA, (0 * A4 + ca) * LDH + ma, ra, x)                                                     \
-        GRL_STORE_RUN(As, NA, (1 * A4 + ca) * LDH + ma, ra, y)                                                     \
-        GRL_STORE_RUN(As, NA, (2 * A4 + ca) * LDH + ma, ra, z)                                                     \
-        GRL_STORE_RUN(As, NA, (3 * A4 + ca) * LDH + ma, ra, w)                                                     \
+        GRL_STORE_RUN(As, NA, GRL_TN_OFF(0 * A4 + ca, ma), ra, x)                                                  \
+        GRL_STORE_RUN(As, NA, GRL_TN_OFF(1 * A4 + ca, ma), ra, y)                                                  \
+        GRL_STORE_RUN(As, NA, GRL_TN_OFF(2 * A4 + ca, ma), ra, z)                                                  \
+        GRL_STORE_RUN(As, NA, GRL_TN_OFF(3 * A4 + ca, ma), ra, w)                                                  \
         _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                           \
             const bool v = (vmb >> i) & 1u;                                                                        \
             float4 t4 = rb[i];                                                                                     \
             t4.x = v ? t4.x : 0.f; t4.y = v ? t4.y : 0.f; t4.z = v ? t4.z : 0.f; t4.w = v ? t4.w : 0.f;            \
             rb[i] = t4;                                                                                            \
         }                                                                                                          \
-        GRL_STORE_RUN(Bs, NB, (0 * B4 + cb) * LDH + mb, rb, x)                                                     \
-        GRL_STORE_RUN(Bs, NB, (1 * B4 + cb) * LDH + mb, rb, y)                                                     \
-        GRL_STORE_RUN(Bs, NB, (2 * B4 + cb) * LDH + mb, rb, z)                                                     \
-        GRL_STORE_RUN(Bs, NB, (3 * B4 + cb) * LDH + mb, rb, w)                                                     \
+        GRL_STORE_RUN(Bs, NB, GRL_TN_OFF(0 * B4 + cb, mb), rb, x)                                                  \
+        GRL_STORE_RUN(Bs, NB, GRL_TN_OFF(1 * B4 + cb, mb), rb, y)                                                  \
+        GRL_STORE_RUN(Bs, NB, GRL_TN_OFF(2 * B4 + cb, mb), rb, z)                                                  \
+        GRL_STORE_RUN(Bs, NB, GRL_TN_OFF(3 * B4 + cb, mb), rb, w)                                                  \
     }
-    f32x16 acc[TM][TN];
+    f32x4 acc[TM][TN];
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
         for (int b = 0; b < TN; ++b)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-    const int lr = lane & 31, lk = lane >> 5;
-    const int aro = (wm * WM + lr) * LDH + lk * 8;
-    const int bro = (wn * WN + lr) * LDH + lk * 8;
+            for (int r = 0; r < 4; ++r) acc[a][b][r] = 0.f;
+    const int l16 = lane & 15, kg = lane >> 4;
+    const int ro = (kg ^ swz(l16)) << 3;
+    const int aro = (wm * WM + l16) * LDH + ro;
+    const int bro = (wn * WN + l16) * LDH + ro;
     if (mbeg < mend) {
         GRL_LOAD_IDX(mbeg)
         GRL_LOAD_TILE()
@@ -663,21 +675,20 @@ __global__ __launch_bounds__(256, 2) void gemm_tn(AG ag, const float *__restrict
             GRL_LOAD_TILE()                  // rows mt + BK .. (row 0, masked, past the end of the range)
             GRL_LOAD_IDX(mt + 2 * BK)
             GRL_SCHED_FENCE
-#pragma unroll
-            for (int s = 0; s < BK / 16; ++s) {
-                bf16x8 af[TM][3], bf[TN][3];
-#pragma unroll
-                for (int a = 0; a < TM; ++a)
-#pragma unroll
-                    for (int p = 0; p < 3; ++p) af[a][p] = *reinterpret_cast<const bf16x8 *>(&As[p][aro + a * 32 * LDH + s * 16]);
+            {
+                bf16x8 bf[TN][3];
 #pragma unroll
                 for (int b = 0; b < TN; ++b)
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) bf[b][p] = *reinterpret_cast<const bf16x8 *>(&Bs[p][bro + b * 32 * LDH + s * 16]);
+                    for (int p = 0; p < 3; ++p) bf[b][p] = *reinterpret_cast<const bf16x8 *>(&Bs[p][bro + b * 16 * LDH]);
 #pragma unroll
-                for (int a = 0; a < TM; ++a)
+                for (int a = 0; a < TM; ++a) {
+                    bf16x8 af[3];
 #pragma unroll
-                    for (int b = 0; b < TN; ++b) mfma_x6(acc[a][b], af[a], bf[b]);
+                    for (int p = 0; p < 3; ++p) af[p] = *reinterpret_cast<const bf16x8 *>(&As[p][aro + a * 16 * LDH]);
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) mfma_x6(acc[a][b], af, bf[b]);
+                }
             }
             GRL_SCHED_FENCE
             __syncthreads();
@@ -689,9 +700,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn(AG ag, const float *__restrict
 #pragma unroll
         for (int b = 0; b < TN; ++b)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int pa = wm * WM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;      // LDS rows -> tile columns
-                const int pb = wn * WN + b * 32 + lr;
+            for (int r = 0; r < 4; ++r) {
+                const int pa = wm * WM + a * 16 + 4 * kg + r;      // LDS rows -> tile columns
+                const int pb = wn * WN + b * 16 + l16;
                 const int row = i0 + 4 * (pa % A4) + pa / A4;
                 const int col = j0 + 4 * (pb % B4) + pb / B4;
                 if (row < I && col < J) out[(long)row * J + col] = acc[a][b][r];
@@ -700,6 +711,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn(AG ag, const float *__restrict
 #undef GRL_LOAD_IDX
 #undef GRL_STORE_TILE
 #undef GRL_STORE_RUN
+#undef GRL_TN_OFF
 }
 
 // dst[i] (+)= sum_c slab[c][i]   (fixed association: 4 strided partial sums, then a fixed tree -> bitwise

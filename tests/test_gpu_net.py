@@ -201,7 +201,12 @@ def test_gradient_paths_agree_at_tile_multiple_sizes():
         got = NN.unflatten_params(g, shapes)
         for name, _ in shapes:
             err = np.abs(got[name] - ref[name]).max() / (np.abs(ref[name]).max() + 1e-12)
-            assert err < 5e-5, (name, err)
+            # dense1's pre-activation is rounded differently by the two evaluations (per-env part + patch part against one
+            # 3136-long sum): of the 1.3 million ReLU inputs a handful sit within that round-off of zero and get the other
+            # mask, each moving the gradients of dense1 and of everything below it by one sample-unit's worth (observed
+            # 3e-5 in dense1, up to 3e-4 in conv1_w, where the sum cancels most); layers above dense1 see no masks flip
+            tol = 1e-3 if name.startswith(("conv", "dense1")) else 5e-6
+            assert err < tol, (name, err)
     for s in stats[:4]:
         np.testing.assert_allclose(s["loss"], stats[4]["loss"], rtol=1e-5)
         np.testing.assert_allclose(s["global_norm"], stats[4]["global_norm"], rtol=1e-5)

@@ -238,6 +238,101 @@ __global__ __launch_bounds__(256, 1) void rowk_x6p(const float *__restrict__ A, 
             }
 }
 
+
+// variant on v_mfma_f32_16x16x32_bf16 (more FLOP per watt than 32x32x16 on toggling data): wave tile 64x64 = 4x4 tiles of
+// 16x16, one K = 32 step per BK tile; LDS rows of 48 bf16 (96 B) make the b128 fragment reads conflict free for this map
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(256, 2) void rowk_x6_16(const float *__restrict__ A, const float *__restrict__ Bt, float *__restrict__ C, int M, int N, int K) {
+    constexpr int BK = 32, LDH = 48;
+    constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 16, TN = WN / 16, NA = BM / 32, NB = BN / 32;
+    __shared__ __attribute__((aligned(16))) unsigned short As[3][BM * LDH];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[3][BN * LDH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave - wm * WGN;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int trow = tid >> 3, tk4 = (tid & 7) * 4;
+    const float *arow = A + (long)(m0 + trow) * K + tk4;
+    const float *brow = Bt + (long)(n0 + trow) * K + tk4;
+    float4 ra[NA], rb[NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const float4 *>(arow + (long)32 * i * K);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const float4 *>(brow + (long)32 * i * K);
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[a][b][r] = 0.f;
+    const int l16 = lane & 15, kg = lane >> 4;
+    const int aro = (wm * WM + l16) * LDH + kg * 8, bro = (wn * WN + l16) * LDH + kg * 8;
+    const int nk = K / BK;
+    for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            uint2 h, m, l;
+            split4(ra[i], h, m, l);
+            const int o = (trow + 32 * i) * LDH + tk4;
+            *reinterpret_cast<uint2 *>(&As[0][o]) = h;
+            *reinterpret_cast<uint2 *>(&As[1][o]) = m;
+            *reinterpret_cast<uint2 *>(&As[2][o]) = l;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            uint2 h, m, l;
+            split4(rb[i], h, m, l);
+            const int o = (trow + 32 * i) * LDH + tk4;
+            *reinterpret_cast<uint2 *>(&Bs[0][o]) = h;
+            *reinterpret_cast<uint2 *>(&Bs[1][o]) = m;
+            *reinterpret_cast<uint2 *>(&Bs[2][o]) = l;
+        }
+        __syncthreads();
+        const int ktn = kt + 1 < nk ? kt + 1 : kt;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const float4 *>(arow + (long)32 * i * K + ktn * BK);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const float4 *>(brow + (long)32 * i * K + ktn * BK);
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            bf16x8 bf[TN][3];
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) bf[b][p] = *reinterpret_cast<const bf16x8 *>(&Bs[p][bro + b * 16 * LDH]);
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                bf16x8 af[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) af[p] = *reinterpret_cast<const bf16x8 *>(&As[p][aro + a * 16 * LDH]);
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2], bf[b][0], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[b][2], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bf[b][1], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bf[b][0], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[b][1], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[b][0], acc[a][b], 0, 0, 0);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+    }
+    // C/D map of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + reg
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int row = m0 + wm * WM + a * 16 + 4 * kg + r;
+                int col = n0 + wn * WN + b * 16 + l16;
+                if (row < M && col < N) C[(long)row * N + col] = acc[a][b][r];
+            }
+}
+
 // the production fp32 loop (net_gemm.h gemm_rowk) on the same dense operands
 template <int BM, int BN, int WGM, int WGN>
 __global__ __launch_bounds__(256, 2) void rowk_f32(const float *__restrict__ A, const float *__restrict__ Bt, float *__restrict__ C, int M, int N, int K) {
@@ -391,6 +486,13 @@ static void run(int M, int N, int K, float scale = 1.f) {
         }
         printf("   mode %d (1: no global loads, 2: no split, 4: no sched barriers; mode 5 = 2-deep prefetch, 6 = 2-deep + no fences): %8.3f ms %7.1f TF\n", mode, ms, flops / ms / 1e9);
     }
+    {
+        dim3 g(N / 128, M / 128);
+        float ms = time_ms([&] { hipLaunchKernelGGL((rowk_x6_16<128, 128, 2, 2>), g, dim3(256), 0, 0, A, B, C, M, N, K); }, 5);
+        (void)hipMemcpy(hC.data(), C, hC.size() * 4, hipMemcpyDeviceToHost);
+        double rms, w = err_vs_double(hA, hB, hC, M, N, K, &rms);
+        printf("M %6d N %4d K %4d  x6 16x16x32  128x128: %8.3f ms %7.1f TF  err/sum|ab| worst %.3g rms %.3g\n", M, N, K, ms, flops / ms / 1e9, w, rms);
+    }
     for (int v = 0; v < 2; ++v) {
         dim3 g(N / 128, M / 128);
         float ms = v == 0 ? time_ms([&] { hipLaunchKernelGGL((rowk_x6p<128, 128, 2, 2, 0>), g, dim3(256), 0, 0, A, B, C, M, N, K); }, 5)
@@ -415,5 +517,6 @@ int main() {
     run(40960, 512, 1600);     // dense1 patch forward: 1280 workgroups = 2.5 rounds of 512
     run(65536, 512, 1600);     // 2048 workgroups = 4 full rounds
     run(65536, 512, 1600, 0.f);     // same on zeros (no operand toggling: clock / power effect)
+    run(409600, 256, 256);
     return 0;
 }
