@@ -37,7 +37,7 @@ VALU_LANE_INSTR_PEAK = 256 * 4 * 16 * 2.4e9
 SWARM_PAIRS_PER_ENV_STEP = 7200      # pair interactions (6400 locust-locust + 800 agent-locust)
 HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3         # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
-MFMA_BF16_PEAK_TFLOPS = 2516.6       # MI355X_MICROARCH.md: dense bf16 matrix peak (v_mfma_f32_32x32x16_bf16, 32 cycles each)
+MFMA_BF16_PEAK_TFLOPS = 2516.6       # MI355X_MICROARCH.md: dense bf16 matrix peak (v_mfma_f32_16x16x32_bf16, 16 cycles each)
 # the GEMMs split every fp32 operand exactly into three bf16 terms and issue SIX bf16 MFMAs per fp32 product block
 # (net_gemm.h), so the matrix pipe bounds the fp32-equivalent rate at 2516.6 / 6
 BF16_PRODUCTS_PER_FP32 = 6
@@ -331,7 +331,7 @@ def main():
                     gtraffic = json.load(f).get("hbm_bytes_per_launch")
             out["roofline"] = {"bound": "mfma",
                                "kernel": "gemm_rowk / gemm_tn (fp32 implicit GEMMs: operands split exactly into 3 bf16 terms, "
-                                         "6 v_mfma_f32_32x32x16_bf16 per K=16 step, fp32 accumulation)",
+                                         "6 v_mfma_f32_16x16x32_bf16 per 16x16 tile and K=32 step, fp32 accumulation)",
                                "achieved": ach, "peak": MFMA_X6_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_X6_PEAK_TFLOPS,
                                "peak_note": "achieved counts ALGORITHMIC fp32 FLOPs (2*M*N*K of the work actually executed); peak = "
                                             "dense bf16 MFMA peak %.1f / %d bf16 products per fp32 product.  The executed bf16 MFMA "
