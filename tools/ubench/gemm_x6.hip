@@ -242,9 +242,10 @@ __global__ __launch_bounds__(256, 1) void rowk_x6p(const float *__restrict__ A, 
 // variant on v_mfma_f32_16x16x32_bf16 (more FLOP per watt than 32x32x16 on toggling data): wave tile 64x64 = 4x4 tiles of
 // 16x16, one K = 32 step per BK tile; LDS rows of 48 bf16 (96 B) make the b128 fragment reads conflict free for this map
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-template <int BM, int BN, int WGM, int WGN>
+__device__ __forceinline__ int swz(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }
+template <int BM, int BN, int WGM, int WGN, bool SWZ = false>
 __global__ __launch_bounds__(256, 2) void rowk_x6_16(const float *__restrict__ A, const float *__restrict__ Bt, float *__restrict__ C, int M, int N, int K) {
-    constexpr int BK = 32, LDH = 48;
+    constexpr int BK = 32, LDH = SWZ ? 32 : 48;
     constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 16, TN = WN / 16, NA = BM / 32, NB = BN / 32;
     __shared__ __attribute__((aligned(16))) unsigned short As[3][BM * LDH];
     __shared__ __attribute__((aligned(16))) unsigned short Bs[3][BN * LDH];
@@ -267,14 +268,16 @@ __global__ __launch_bounds__(256, 2) void rowk_x6_16(const float *__restrict__ A
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[a][b][r] = 0.f;
     const int l16 = lane & 15, kg = lane >> 4;
-    const int aro = (wm * WM + l16) * LDH + kg * 8, bro = (wn * WN + l16) * LDH + kg * 8;
+    const int rofs = SWZ ? ((kg ^ swz(l16)) << 3) : kg * 8;
+    const int wo = SWZ ? ((((tk4 >> 3) ^ swz(trow)) << 3) + (tk4 & 4)) : tk4;
+    const int aro = (wm * WM + l16) * LDH + rofs, bro = (wn * WN + l16) * LDH + rofs;
     const int nk = K / BK;
     for (int kt = 0; kt < nk; ++kt) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             uint2 h, m, l;
             split4(ra[i], h, m, l);
-            const int o = (trow + 32 * i) * LDH + tk4;
+            const int o = (trow + 32 * i) * LDH + wo;
             *reinterpret_cast<uint2 *>(&As[0][o]) = h;
             *reinterpret_cast<uint2 *>(&As[1][o]) = m;
             *reinterpret_cast<uint2 *>(&As[2][o]) = l;
@@ -283,7 +286,7 @@ __global__ __launch_bounds__(256, 2) void rowk_x6_16(const float *__restrict__ A
         for (int i = 0; i < NB; ++i) {
             uint2 h, m, l;
             split4(rb[i], h, m, l);
-            const int o = (trow + 32 * i) * LDH + tk4;
+            const int o = (trow + 32 * i) * LDH + wo;
             *reinterpret_cast<uint2 *>(&Bs[0][o]) = h;
             *reinterpret_cast<uint2 *>(&Bs[1][o]) = m;
             *reinterpret_cast<uint2 *>(&Bs[2][o]) = l;
@@ -492,6 +495,20 @@ static void run(int M, int N, int K, float scale = 1.f) {
         (void)hipMemcpy(hC.data(), C, hC.size() * 4, hipMemcpyDeviceToHost);
         double rms, w = err_vs_double(hA, hB, hC, M, N, K, &rms);
         printf("M %6d N %4d K %4d  x6 16x16x32  128x128: %8.3f ms %7.1f TF  err/sum|ab| worst %.3g rms %.3g\n", M, N, K, ms, flops / ms / 1e9, w, rms);
+    }
+    {
+        dim3 g(N / 128, M / 128);
+        float ms = time_ms([&] { hipLaunchKernelGGL((rowk_x6_16<128, 128, 2, 2, true>), g, dim3(256), 0, 0, A, B, C, M, N, K); }, 5);
+        (void)hipMemcpy(hC.data(), C, hC.size() * 4, hipMemcpyDeviceToHost);
+        double rms, w = err_vs_double(hA, hB, hC, M, N, K, &rms);
+        printf("M %6d N %4d K %4d  x6 16x16x32 swizzled 128x128: %8.3f ms %7.1f TF  err/sum|ab| worst %.3g rms %.3g\n", M, N, K, ms, flops / ms / 1e9, w, rms);
+    }
+    {
+        dim3 g(N / 64, M / 256);
+        float ms = time_ms([&] { hipLaunchKernelGGL((rowk_x6_16<256, 64, 4, 1, true>), g, dim3(256), 0, 0, A, B, C, M, N, K); }, 5);
+        (void)hipMemcpy(hC.data(), C, hC.size() * 4, hipMemcpyDeviceToHost);
+        double rms, w = err_vs_double(hA, hB, hC, M, N, K, &rms);
+        printf("M %6d N %4d K %4d  x6 16x16x32 swizzled 256x64 : %8.3f ms %7.1f TF  err/sum|ab| worst %.3g rms %.3g\n", M, N, K, ms, flops / ms / 1e9, w, rms);
     }
     for (int v = 0; v < 2; ++v) {
         dim3 g(N / 128, M / 128);
