@@ -264,6 +264,12 @@ struct PatchRows {
 };
 
 // ---------------------------------------------------------------------------- epilogues
+// An epilogue is evaluated in two passes so that every load it needs is in flight before the first store is issued
+// (stores and loads through unrelated pointers cannot be reordered by the compiler: one load -> select -> store chain per
+// element serialises 64 memory round trips per lane, which cost the K = 256 data-gradient GEMMs 40 % of their time):
+//   row_aux(r)            per output row: index indirections (sorted row -> sample)
+//   elem_aux(r, c, ra)    per output element: ReLU mask source, per-env term, bias
+//   store(r, c, v, ra, ea)
 enum { ACT_NONE = 0, ACT_RELU = 1 };
 
 struct EpiBiasAct {   // C[r][c] = act(v + bias[c])
@@ -271,8 +277,10 @@ struct EpiBiasAct {   // C[r][c] = act(v + bias[c])
     int ldc;
     const float *bias;
     int act;
-    __device__ __forceinline__ void operator()(int r, int c, float v) const {
-        v += bias[c];
+    __device__ __forceinline__ int row_aux(int) const { return 0; }
+    __device__ __forceinline__ float elem_aux(int, int c, int) const { return bias[c]; }
+    __device__ __forceinline__ void store(int r, int c, float v, int, float ea) const {
+        v += ea;
         if (act == ACT_RELU) v = fmaxf(v, 0.f);
         C[(long)r * ldc + c] = v;
     }
@@ -283,9 +291,10 @@ struct EpiPatchFwd {   // sorted row -> sample m: out[m][c] = relu(v + ysh[env(m
     const float *ysh;
     const int *perm;
     int ld;
-    __device__ __forceinline__ void operator()(int r, int c, float v) const {
-        const int m = perm[r];
-        if (m >= 0) out[(long)m * ld + c] = fmaxf(v + ysh[(long)(m / 10) * ld + c], 0.f);
+    __device__ __forceinline__ int row_aux(int r) const { return perm[r]; }
+    __device__ __forceinline__ float elem_aux(int, int c, int m) const { return ysh[(long)(max(m, 0) / 10) * ld + c]; }     // padding rows (m < 0) read env 0, unused
+    __device__ __forceinline__ void store(int, int c, float v, int m, float ea) const {
+        if (m >= 0) out[(long)m * ld + c] = fmaxf(v + ea, 0.f);
     }
 };
 
@@ -293,48 +302,61 @@ struct EpiPermStore {   // sorted row -> sample m: out[m][c] = v
     float *out;
     const int *perm;
     int ld;
-    __device__ __forceinline__ void operator()(int r, int c, float v) const {
-        const int m = perm[r];
+    __device__ __forceinline__ int row_aux(int r) const { return perm[r]; }
+    __device__ __forceinline__ float elem_aux(int, int, int) const { return 0.f; }
+    __device__ __forceinline__ void store(int, int c, float v, int m, float) const {
         if (m >= 0) out[(long)m * ld + c] = v;
     }
 };
 
-struct EpiGrad {   // dX[r][c] = (v [+ dX[r][c]]) * (fwd[r][c] > 0 if mask)
+struct EpiGrad {   // dX[r][c] = v * (fwd[r][c] > 0): data gradient with the ReLU mask of the forward tensor fused
     float *dX;
     int ld;
-    const float *fwd;   // forward activation of the same tensor (post-ReLU), or nullptr
-    int accumulate;
-    __device__ __forceinline__ void operator()(int r, int c, float v) const {
-        long i = (long)r * ld + c;
-        if (accumulate) v += dX[i];
-        if (fwd) v = fwd[i] > 0.f ? v : 0.f;
-        dX[i] = v;
-    }
+    const float *fwd;   // forward activation of the same tensor (post-ReLU)
+    __device__ __forceinline__ int row_aux(int) const { return 0; }
+    __device__ __forceinline__ float elem_aux(int r, int c, int) const { return fwd[(long)r * ld + c]; }
+    __device__ __forceinline__ void store(int r, int c, float v, int, float ea) const { dX[(long)r * ld + c] = ea > 0.f ? v : 0.f; }
+};
+
+struct EpiStore {   // dX[r][c] = v
+    float *dX;
+    int ld;
+    __device__ __forceinline__ int row_aux(int) const { return 0; }
+    __device__ __forceinline__ float elem_aux(int, int, int) const { return 0.f; }
+    __device__ __forceinline__ void store(int r, int c, float v, int, float) const { dX[(long)r * ld + c] = v; }
 };
 
 struct EpiGradPM {   // pixel-major rows (r = q*nsamp + n) -> dX[n][q][c], ReLU mask of the forward tensor fused
     float *dX;
     const float *fwd;
     int nsamp, pps, ld;
-    __device__ __forceinline__ void operator()(int r, int c, float v) const {
+    __device__ __forceinline__ int row_aux(int r) const {      // element offset of the row (< 2^31: 40 960 x 81 x 64)
         int q = r / nsamp, n = r - q * nsamp;
-        long i = ((long)n * pps + q) * ld + c;
-        dX[i] = fwd[i] > 0.f ? v : 0.f;
+        return (n * pps + q) * ld;
     }
+    __device__ __forceinline__ float elem_aux(int, int c, int base) const { return fwd[(long)base + c]; }
+    __device__ __forceinline__ void store(int, int c, float v, int base, float ea) const { dX[(long)base + c] = ea > 0.f ? v : 0.f; }
 };
 
 // data gradient of conv2: the four pixel-parity classes (py,px) read the SAME 2x2 source taps and differ
 // only in their kernel, so they are the N = 4*32 columns of one GEMM: row (n, yh, xh), column cls*32 + c
 // -> pixel (2yh+py, 2xh+px), channel c of the [n][20][20][32] tensor
+template <bool MASK>
 struct EpiGradStride2 {
     float *dX;
-    const float *fwd;
-    __device__ __forceinline__ void operator()(int r, int col, float v) const {
+    const float *fwd;     // MASK = false: raw transposed convolution (shared-trunk mode), fwd unused
+    __device__ __forceinline__ int row_aux(int r) const {      // offset of pixel (2yh, 2xh) (< 2^31: 40 960 x 12 800)
         int n = r / 100, q = r - n * 100;
         int yh = q / 10, xh = q - yh * 10;
+        return ((n * 20 + 2 * yh) * 20 + 2 * xh) * 32;
+    }
+    __device__ __forceinline__ int col_off(int col) const {
         int cls = col >> 5, c = col & 31;
-        long i = (((long)n * 20 + 2 * yh + (cls >> 1)) * 20 + 2 * xh + (cls & 1)) * 32 + c;
-        dX[i] = fwd ? (fwd[i] > 0.f ? v : 0.f) : v;     // fwd == nullptr: raw transposed convolution (shared-trunk mode)
+        return ((cls >> 1) * 20 + (cls & 1)) * 32 + c;
+    }
+    __device__ __forceinline__ float elem_aux(int, int c, int base) const { return MASK ? fwd[(long)base + col_off(c)] : 0.f; }
+    __device__ __forceinline__ void store(int, int c, float v, int base, float ea) const {
+        dX[(long)base + col_off(c)] = (!MASK || ea > 0.f) ? v : 0.f;
     }
 };
 
@@ -519,16 +541,32 @@ __global__ __launch_bounds__(256, 2) void gemm_rowk(AG ag, const float *__restri
         __syncthreads();
         kt = ktn;
     }
-    // C/D map of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + reg
+    // C/D map of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + reg.  Two passes: all of the epilogue's loads, then
+    // the stores (see the epilogue structs).
+    const int erow = m0 + wm * WM + 4 * kg, ecol = n0 + wn * WN + l16;
+    int rax[TM][4];
+    float eax[TM][TN][4];
+    // the loads are unconditional on clamped coordinates: a per-element predicate would wrap every load in its own
+    // exec-mask block with a wait behind it
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rax[a][r] = epi.row_aux(min(erow + a * 16 + r, M - 1));
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                eax[a][b][r] = epi.elem_aux(min(erow + a * 16 + r, M - 1), min(ecol + b * 16, N - 1), rax[a][r]);
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
         for (int b = 0; b < TN; ++b)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                int row = m0 + wm * WM + a * 16 + 4 * kg + r;
-                int col = n0 + wn * WN + b * 16 + l16;
-                if (row < M && col < N) epi(row, col, acc[a][b][r]);
+                const int row = erow + a * 16 + r, col = ecol + b * 16;
+                if (row < M && col < N) epi.store(row, col, acc[a][b][r], rax[a][r], eax[a][b][r]);
             }
 #undef GRL_LOAD_TILE
 #undef GRL_STORE_TILE

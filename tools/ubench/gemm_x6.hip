@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256, 1) void rowk_x6p(const float *__restrict__ A, 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ int swz(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }
 template <int BM, int BN, int WGM, int WGN, bool SWZ = false>
-__global__ __launch_bounds__(256, 2) void rowk_x6_16(const float *__restrict__ A, const float *__restrict__ Bt, float *__restrict__ C, int M, int N, int K) {
+__global__ __launch_bounds__(256, 2) void rowk_x6_16(const float *__restrict__ A, const float *__restrict__ Bt, float *__restrict__ C, int M, int N, int K, const float *__restrict__ fwd = nullptr) {
     constexpr int BK = 32, LDH = SWZ ? 32 : 48;
     constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 16, TN = WN / 16, NA = BM / 32, NB = BN / 32;
     __shared__ __attribute__((aligned(16))) unsigned short As[3][BM * LDH];
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256, 2) void rowk_x6_16(const float *__restrict__ A
             for (int r = 0; r < 4; ++r) {
                 int row = m0 + wm * WM + a * 16 + 4 * kg + r;
                 int col = n0 + wn * WN + b * 16 + l16;
-                if (row < M && col < N) C[(long)row * N + col] = acc[a][b][r];
+                if (row < M && col < N) { float v = acc[a][b][r]; if (fwd) v = fwd[(long)row * N + col] > 0.f ? v : 0.f; C[(long)row * N + col] = v; }
             }
 }
 
@@ -504,6 +504,15 @@ static void run(int M, int N, int K, float scale = 1.f) {
         printf("M %6d N %4d K %4d  x6 16x16x32 swizzled 128x128: %8.3f ms %7.1f TF  err/sum|ab| worst %.3g rms %.3g\n", M, N, K, ms, flops / ms / 1e9, w, rms);
     }
     {
+        float *F;
+        (void)hipMalloc(&F, hC.size() * 4);
+        (void)hipMemcpy(F, hA.data(), (hC.size() < hA.size() ? hC.size() : hA.size()) * 4, hipMemcpyHostToDevice);
+        dim3 g(N / 128, M / 128);
+        float ms = time_ms([&] { hipLaunchKernelGGL((rowk_x6_16<128, 128, 2, 2, true>), g, dim3(256), 0, 0, A, B, C, M, N, K, F); }, 5);
+        printf("M %6d N %4d K %4d  x6 16x16x32 swizzled 128x128 + ReLU-mask epilogue: %8.3f ms %7.1f TF\n", M, N, K, ms, flops / ms / 1e9);
+        (void)hipFree(F);
+    }
+    {
         dim3 g(N / 64, M / 256);
         float ms = time_ms([&] { hipLaunchKernelGGL((rowk_x6_16<256, 64, 4, 1, true>), g, dim3(256), 0, 0, A, B, C, M, N, K); }, 5);
         (void)hipMemcpy(hC.data(), C, hC.size() * 4, hipMemcpyDeviceToHost);
@@ -531,9 +540,8 @@ static void run(int M, int N, int K, float scale = 1.f) {
 }
 
 int main() {
-    run(40960, 512, 1600);     // dense1 patch forward: 1280 workgroups = 2.5 rounds of 512
-    run(65536, 512, 1600);     // 2048 workgroups = 4 full rounds
-    run(65536, 512, 1600, 0.f);     // same on zeros (no operand toggling: clock / power effect)
-    run(409600, 256, 256);
+    run(40960, 512, 256);      // dense2 data gradient: K = 256, N = 512
+    run(40960, 256, 1024);     // pol1 | v1 pair
+    run(40960, 512, 1600);
     return 0;
 }
