@@ -69,6 +69,7 @@ struct NetLane {
     float *a3sh, *d3, *v3, *ysh;
     float *gd1sh, *gsh3, *g3p, *dz3p;     // gradient side: per-env sum of gd1, its dense1 data gradient, per-agent patch gradients
     int *perm, *goffp, *blkcnt, *blkoff, *sbeg, *send, *sgrp;
+    int2 *rowdesc;                     // gather descriptors of the compact slot rows (slot_rowdesc_kernel)
     int *sbase, *rowagent, *sblk;      // compact slot rows (net_shared.inc): prefix of per-sample slot counts, row -> sample, scan scratch
     signed char *tilegroup, *org;
     signed char *ulist;
@@ -510,6 +511,7 @@ static int alloc_lane_forward(grl_net *n) {
     if (rc == GRL_OK) rc = nalloc(n, &n->org, c);
     if (rc == GRL_OK) rc = nalloc(n, &n->sbase, c + 1);
     if (rc == GRL_OK) rc = nalloc(n, &n->rowagent, c * 9);
+    if (rc == GRL_OK) rc = nalloc(n, &n->rowdesc, c * 9);
     if (rc == GRL_OK) rc = nalloc(n, &n->sblk, 1024);
     return rc;
 }

@@ -71,8 +71,11 @@ struct ConvGather {
     __device__ __forceinline__ bool tile_active(int) const { return true; }
     __device__ __forceinline__ int bk(int k0, int) const { return k0; }
     __device__ __forceinline__ int bn(int n0, int) const { return n0; }
-    __device__ __forceinline__ int rowidx(int m) const { return m; }
-    __device__ __forceinline__ void rowp(int p, long &off, int &iy0, int &ix0) const { row(p, off, iy0, ix0); }
+    // gemm_tn: row handles are fetched one tile ahead of the data (ahandle / bhandle may load), rowh is arithmetic only
+    __device__ __forceinline__ int2 ahandle(int m) const { return make_int2(m, 0); }
+    __device__ __forceinline__ bool hvalid(int2) const { return true; }
+    __device__ __forceinline__ int bhandle(int m) const { return m; }
+    __device__ __forceinline__ void rowh(int2 h, long &off, int &iy0, int &ix0) const { row(h.x, off, iy0, ix0); }
     __device__ __forceinline__ void mrange(int z, int mc, int &mbeg, int &mend) const { mbeg = z * mc; mend = min(rows, mbeg + mc); }
 };
 
@@ -111,8 +114,11 @@ struct ConvGatherPM {
     __device__ __forceinline__ bool tile_active(int) const { return true; }
     __device__ __forceinline__ int bk(int k0, int) const { return k0; }
     __device__ __forceinline__ int bn(int n0, int) const { return n0; }
-    __device__ __forceinline__ int rowidx(int m) const { return m; }
-    __device__ __forceinline__ void rowp(int p, long &off, int &iy0, int &ix0) const { row(p, off, iy0, ix0); }
+    // gemm_tn: row handles are fetched one tile ahead of the data (ahandle / bhandle may load), rowh is arithmetic only
+    __device__ __forceinline__ int2 ahandle(int m) const { return make_int2(m, 0); }
+    __device__ __forceinline__ bool hvalid(int2) const { return true; }
+    __device__ __forceinline__ int bhandle(int m) const { return m; }
+    __device__ __forceinline__ void rowh(int2 h, long &off, int &iy0, int &ix0) const { row(h.x, off, iy0, ix0); }
     __device__ __forceinline__ void mrange(int z, int mc, int &mbeg, int &mend) const { mbeg = z * mc; mend = min(rows, mbeg + mc); }
 };
 
@@ -135,8 +141,11 @@ struct DenseRows {   // plain row-major [rows][ld], reduction length k
     __device__ __forceinline__ bool tile_active(int m0) const { return !rows_dev || m0 < *rows_dev; }
     __device__ __forceinline__ int bk(int k0, int) const { return k0; }
     __device__ __forceinline__ int bn(int n0, int) const { return n0; }
-    __device__ __forceinline__ int rowidx(int m) const { return m; }
-    __device__ __forceinline__ void rowp(int p, long &off, int &iy0, int &ix0) const { row(p, off, iy0, ix0); }
+    // gemm_tn: row handles are fetched one tile ahead of the data (ahandle / bhandle may load), rowh is arithmetic only
+    __device__ __forceinline__ int2 ahandle(int m) const { return make_int2(m, 0); }
+    __device__ __forceinline__ bool hvalid(int2) const { return true; }
+    __device__ __forceinline__ int bhandle(int m) const { return m; }
+    __device__ __forceinline__ void rowh(int2 h, long &off, int &iy0, int &ix0) const { row(h.x, off, iy0, ix0); }
     __device__ __forceinline__ void mrange(int z, int mc, int &mbeg, int &mend) const { mbeg = z * mc; mend = min(rows, mbeg + mc); }
 };
 
@@ -162,8 +171,11 @@ struct DenseRowsPair {
     __device__ __forceinline__ bool tile_active(int) const { return true; }
     __device__ __forceinline__ int bk(int k0, int) const { return k0 < half ? k0 : bdelta + (k0 - half); }
     __device__ __forceinline__ int bn(int n0, int) const { return n0; }
-    __device__ __forceinline__ int rowidx(int m) const { return m; }
-    __device__ __forceinline__ void rowp(int p, long &off, int &iy0, int &ix0) const { row(p, off, iy0, ix0); }
+    // gemm_tn: row handles are fetched one tile ahead of the data (ahandle / bhandle may load), rowh is arithmetic only
+    __device__ __forceinline__ int2 ahandle(int m) const { return make_int2(m, 0); }
+    __device__ __forceinline__ bool hvalid(int2) const { return true; }
+    __device__ __forceinline__ int bhandle(int m) const { return m; }
+    __device__ __forceinline__ void rowh(int2 h, long &off, int &iy0, int &ix0) const { row(h.x, off, iy0, ix0); }
     __device__ __forceinline__ void mrange(int z, int mc, int &mbeg, int &mend) const { mbeg = z * mc; mend = min(rows, mbeg + mc); }
 };
 
@@ -176,19 +188,18 @@ struct DenseRowsPair {
 struct SlotGatherT3P {
     static constexpr bool kRelu = false;
     const float *base;
-    const signed char *ulist, *org;
+    const int2 *rowdesc;         // per compact slot row: {element offset of tap (0,0) in base, (iy0 << 16) | (ix0 & 0xffff)}; dead rows
+                                 // carry iy0 = ix0 = -16 (every tap outside).  Built by slot_rowdesc_kernel (net_shared.inc)
+                                 // so that the gather needs ONE index load per row instead of the chain row -> sample -> origin
     int rows;                    // upper bound (9 per sample); the live count is *rows_dev
-    const int *rowagent;         // compact slot row -> sample
     const int *rows_dev;
     __device__ __forceinline__ int K() const { return 576; }
-    __device__ __forceinline__ void row(int r, long &off, int &iy0, int &ix0) const {
-        const bool live = r < *rows_dev;
-        const int n = live ? rowagent[r] : 0, u = live ? ulist[r] : -1, g = org[n];
-        const int qy = u / 9, qx = u - qy * 9, oy = g / 3, ox = g - oy * 3;
-        iy0 = u < 0 ? -16 : qy - 2;
-        ix0 = u < 0 ? -16 : qx - 2;
-        off = (long)n * 1600 + ((long)(iy0 - oy) * 5 + (ix0 - ox)) * 64;
+    __device__ __forceinline__ void rowh(int2 d, long &off, int &iy0, int &ix0) const {
+        off = d.x;
+        iy0 = d.y >> 16;
+        ix0 = (int)(int16_t)(d.y & 0xFFFF);
     }
+    __device__ __forceinline__ void row(int r, long &off, int &iy0, int &ix0) const { rowh(rowdesc[r], off, iy0, ix0); }
     __device__ __forceinline__ void tap(int k0, int &toff, int &ty, int &tx) const {
         int t = k0 >> 6;
         int c0 = k0 & 63;
@@ -203,8 +214,10 @@ struct SlotGatherT3P {
     __device__ __forceinline__ bool tile_active(int m0) const { return m0 < *rows_dev; }
     __device__ __forceinline__ int bk(int k0, int) const { return k0; }
     __device__ __forceinline__ int bn(int n0, int) const { return n0; }
-    __device__ __forceinline__ int rowidx(int m) const { return m; }
-    __device__ __forceinline__ void rowp(int p, long &off, int &iy0, int &ix0) const { row(p, off, iy0, ix0); }
+    // gemm_tn: row handles are fetched one tile ahead of the data (ahandle / bhandle may load), rowh is arithmetic only
+    __device__ __forceinline__ int2 ahandle(int m) const { return rowdesc[m]; }
+    __device__ __forceinline__ bool hvalid(int2) const { return true; }      // the offset of tap (0,0) may be negative
+    __device__ __forceinline__ int bhandle(int m) const { return m; }
     __device__ __forceinline__ void mrange(int z, int mc, int &mbeg, int &mend) const {
         mbeg = z * mc;
         mend = min(*rows_dev, mbeg + mc);
@@ -225,11 +238,13 @@ struct PatchRows {
     const signed char *tilegroup;
     int rows, ld, k, mode;
     const int *sbeg, *send;      // gemm_tn only: grid z = slice of <= 1024 sorted rows inside one group (empty: sbeg == send)
-    __device__ __forceinline__ int rowidx(int m) const { return perm[m]; }      // gemm_tn: fetched one tile ahead
-    __device__ __forceinline__ void rowp(int p, long &off, int &iy0, int &ix0) const {
+    __device__ __forceinline__ int2 ahandle(int m) const { return make_int2(perm[m], 0); }      // gemm_tn: fetched one tile ahead
+    __device__ __forceinline__ bool hvalid(int2 h) const { return h.x >= 0; }                     // padding rows of the sorted layout
+    __device__ __forceinline__ int bhandle(int m) const { return perm[m]; }
+    __device__ __forceinline__ void rowh(int2 h, long &off, int &iy0, int &ix0) const {
         iy0 = 0;
         ix0 = 0;
-        off = (long)p * ld;
+        off = (long)h.x * ld;
     }
     __device__ __forceinline__ void mrange(int z, int, int &mbeg, int &mend) const {
         mbeg = sbeg[z];
@@ -619,24 +634,28 @@ __global__ __launch_bounds__(256, 2) void gemm_tn(AG ag, const float *__restrict
     unsigned vma = 0, vmb = 0;
     // physical rows of the tile about to be loaded (-1: past the range / padding).  They are fetched one tile ahead of
     // the data so that an indirection (PatchRows' sorted order) does not put two dependent global loads in one stage.
-    int ia[NA], ib[NB];
+    int2 ia[NA];
+    int ib[NB];
+    unsigned iva = 0;      // which handles in ia name a row inside the range (and not a padding row)
 #define GRL_LOAD_IDX(mt_)                                                                                          \
     {                                                                                                              \
         _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                           \
             const int m = (mt_) + ma + i;                                                                          \
-            ia[i] = m < mend ? ag.rowidx(m) : -1;                                                                  \
+            ia[i] = ag.ahandle(m < mend ? m : mbeg);                                                               \
+            iva = (m < mend && ag.hvalid(ia[i])) ? (iva | (1u << i)) : (iva & ~(1u << i));                         \
         }                                                                                                          \
         _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                           \
             const int m = (mt_) + mb + i;                                                                          \
-            ib[i] = m < mend ? ag.rowidx(m) : -1;                                                                  \
+            ib[i] = ag.bhandle(m < mend ? m : mbeg);                                                               \
+            if (m >= mend) ib[i] = -1;                                                                             \
         }                                                                                                          \
     }
 #define GRL_LOAD_TILE()                                                                                            \
     {                                                                                                              \
         _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                           \
-            const bool inr = ia[i] >= 0;                                                                           \
+            const bool inr = (iva >> i) & 1u;                                                                      \
             long off; int iy0, ix0;                                                                                \
-            ag.rowp(inr ? ia[i] : 0, off, iy0, ix0);                                                               \
+            ag.rowh(ia[i], off, iy0, ix0);                                                                         \
             const bool v = inr && ag.ok(iy0, ix0, ty, tx);                                                         \
             ra[i] = *reinterpret_cast<const float4 *>(ag.base + (v ? off + toff : 0L) + ca * 4);                   \
             vma = v ? (vma | (1u << i)) : (vma & ~(1u << i));                                                      \
