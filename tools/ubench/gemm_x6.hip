@@ -1,8 +1,15 @@
 // microbenchmark: fp32 GEMM C = A * Bt^T computed on the bf16 matrix pipe with no loss of input precision.
 // Every fp32 operand is split EXACTLY into three bf16 terms x = h + m + l (8 + 8 + 8 significand bits, by truncation);
 // six of the nine partial products (hh, hm, mh, mm, hl, lh -- everything down to 2^-24 |a||b|) are accumulated in fp32
-// by v_mfma_f32_32x32x16_bf16, which runs 16x the rate of v_mfma_f32_32x32x2_f32: 6 instructions replace 8.
-// Compares speed and error (against a double-precision CPU reference) with the plain fp32-MFMA loop.
+// by the bf16 MFMA, which runs 16x the rate of v_mfma_f32_32x32x2_f32: 6 instructions replace 8.
+// Compares speed and error (against a double-precision CPU reference) of
+//   rowk_f32      the plain fp32-MFMA loop (the first version of net_gemm.h)
+//   rowk_x6       six products on v_mfma_f32_32x32x16_bf16, padded 80-byte LDS rows; MODE bits switch off global loads /
+//                 the split / the scheduling fences (what each ingredient costs)
+//   rowk_x6p      the same software-pipelined over two LDS buffers, one workgroup per CU (not faster)
+//   rowk_x6_16    six products on v_mfma_f32_16x16x32_bf16 (what net_gemm.h uses), padded 96-byte rows or the XOR-swizzled
+//                 64-byte rows, optionally with the ReLU-mask epilogue of the data-gradient GEMMs
+// Build: hipcc -O3 --offload-arch=gfx950 gemm_x6.hip -o gemm_x6
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
