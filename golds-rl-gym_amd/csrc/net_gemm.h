@@ -149,6 +149,38 @@ struct DenseRows {   // plain row-major [rows][ld], reduction length k
     __device__ __forceinline__ void mrange(int z, int mc, int &mbeg, int &mend) const { mbeg = z * mc; mend = min(rows, mbeg + mc); }
 };
 
+// `groups` row-major [npad][ld] operands stacked along M (rows = groups * npad, the first `nlive` rows of each live), every one
+// against its own `bnstep`-row block of Bt -- the four conv1-pixel parity classes of the conv2 corrections in ONE launch
+// instead of four launch-latency-bound ones.  gemm_tn: grid z = group * cpc + c reduces rows [c*mc, (c+1)*mc) of its group.
+struct DenseRowsGroups {
+    static constexpr bool kRelu = false;
+    const float *base;
+    int rows, ld, k, npad, nlive, bnstep, cpc;
+    __device__ __forceinline__ int K() const { return k; }
+    __device__ __forceinline__ void row(int r, long &off, int &iy0, int &ix0) const {
+        off = (long)r * ld;
+        iy0 = ix0 = 0;
+    }
+    __device__ __forceinline__ void tap(int k0, int &toff, int &ty, int &tx) const {
+        toff = k0;
+        ty = tx = 0;
+    }
+    __device__ __forceinline__ bool ok(int, int, int, int) const { return true; }
+    __device__ __forceinline__ bool tile_ok(int, int) const { return true; }
+    __device__ __forceinline__ bool tile_active(int m0) const { return m0 % npad < nlive; }      // padding tiles of a group
+    __device__ __forceinline__ int bk(int k0, int) const { return k0; }
+    __device__ __forceinline__ int bn(int n0, int m0) const { return n0 + (m0 / npad) * bnstep; }
+    __device__ __forceinline__ int2 ahandle(int m) const { return make_int2(m, 0); }
+    __device__ __forceinline__ bool hvalid(int2) const { return true; }
+    __device__ __forceinline__ int bhandle(int m) const { return m; }
+    __device__ __forceinline__ void rowh(int2 h, long &off, int &iy0, int &ix0) const { row(h.x, off, iy0, ix0); }
+    __device__ __forceinline__ void mrange(int z, int mc, int &mbeg, int &mend) const {
+        const int g = z / cpc, c = z - g * cpc;
+        mbeg = g * npad + c * mc;
+        mend = min(g * npad + nlive, mbeg + mc);
+    }
+};
+
 // Two row-major [rows][ld] operands side by side along K (k < half from base, k >= half from base + delta), multiplied against
 // two weight matrices stacked the same way (Bt's k offset jumps by bdelta at k = half): dX = [dY1 | dY2] . [W1 | W2]^T in one
 // pass instead of two accumulating ones (pol1 / v1 both feed dense2's output).
@@ -787,6 +819,25 @@ __global__ void slab_reduce_kernel(const float *__restrict__ slab, int chunks, l
     for (; c < chunks; ++c) s0 += slab[(long)c * n + i];
     float s = (s0 + s1) + (s2 + s3);
     dst[i] = accumulate ? dst[i] + s : s;
+}
+
+// groups of slabs reduced in one launch: dst[g][i] (+)= sum_c slab[g * chunks + c][i]
+__global__ void slab_reduce_groups_kernel(const float *__restrict__ slab, int chunks, int n, int groups, float *__restrict__ dst, int accumulate) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= groups * n) return;
+    const int g = e / n, i = e - g * n;
+    const float *sl = slab + (long)g * chunks * n + i;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int c = 0;
+    for (; c + 3 < chunks; c += 4) {
+        s0 += sl[(long)c * n];
+        s1 += sl[(long)(c + 1) * n];
+        s2 += sl[(long)(c + 2) * n];
+        s3 += sl[(long)(c + 3) * n];
+    }
+    for (; c < chunks; ++c) s0 += sl[(long)c * n];
+    const float s = (s0 + s1) + (s2 + s3);
+    dst[e] = accumulate ? dst[e] + s : s;
 }
 
 // Same for a short row (n up to a few thousand) and many chunks, where one lane per element would walk the chunks
