@@ -66,7 +66,8 @@ struct NetLane {
     float *z3sh;
     // dense1 on the shared a3 (net_patch.inc): per-env a3sh and ysh = W^T a3sh + b; per agent the 5x5 patch values v3 and
     // differences d3 (1600 floats); group-sorted sample order for the patch GEMMs
-    float *a3sh, *d3, *v3, *ysh;
+    float *a3sh, *d3, *ysh;
+    unsigned long long *m3;    // ReLU mask of the agent's 5x5 patch of a3: 25 words of 64 channel bits per sample
     float *gd1sh, *gsh3, *g3p, *dz3p;     // gradient side: per-env sum of gd1, its dense1 data gradient, per-agent patch gradients
     int *perm, *goffp, *blkcnt, *blkoff, *sbeg, *send, *sgrp;
     int2 *rowdesc;                     // gather descriptors of the compact slot rows (slot_rowdesc_kernel)
@@ -77,7 +78,8 @@ struct NetLane {
     float *slab1h;             // one-hot conv1 tap partials of agent_ds_kernel
     double *slab64;
     float *ro_mu;              // chunk-sized scratch of the gradient step (cmu csigma cvs dzh cact cadv cy)
-    float *ws_a3, *ws_d1, *ws_d2, *ws_p1, *ws_v1, *ws_v2, *ws_a3sh, *ws_d3, *ws_v3;   // chunk workspace (the default binding)
+    float *ws_a3, *ws_d1, *ws_d2, *ws_p1, *ws_v1, *ws_v2, *ws_a3sh, *ws_d3;   // chunk workspace (the default binding)
+    unsigned long long *ws_m3;
     float *ws_sraw, *ws_a2sh, *ws_d2s, *ws_v2s;
     signed char *ws_ulist;
     bool train_ready;
@@ -367,12 +369,12 @@ __global__ void sample_actions_kernel(const float *__restrict__ mu, const float 
 #include "net_patch.inc"
 
 // ------------------------------------------------------------------------------------------ forward pass of one chunk
-// floats kept per chunk slot: per-agent-trunk mode a3 + dense stack; shared mode a3sh (per env) + d3 + v3 + dense stack,
+// floats kept per chunk slot: per-agent-trunk mode a3 + dense stack; shared mode a3sh (per env) + d3 + patch mask + dense stack,
 // and at level 2 also what the gradient step reads of the per-env trunk: sraw, a2sh (per env), d2s, v2s, ulist (per slot)
 static size_t keep_floats_per_slot(const grl_net *net, int level) {
     const size_t c = net->chunk, dense = 512 + 256 + 512 + 512 + 256;
     if (!net->shared_trunk) return c * (3136 + dense);
-    size_t f = (c / 10) * 3136 + c * (1600 + 1600 + dense);
+    size_t f = (c / 10) * 3136 + c * (1600 + 50 + dense);      // m3: 25 x 8 bytes per sample
     if (level >= 2) f += (c / 10) * (12800 + 5184) + c * (576 + 576) + ((c * 9 + 3) / 4 + 3) / 4 * 4;      // stays a multiple of 16 bytes
     return f;
 }
@@ -381,7 +383,7 @@ static size_t keep_floats_per_slot(const grl_net *net, int level) {
 // workspace for slot < 0
 static void bind_activations(grl_net *net, long slot) {
     net->a3 = net->ws_a3; net->d1 = net->ws_d1; net->d2 = net->ws_d2; net->p1 = net->ws_p1; net->v1 = net->ws_v1; net->v2 = net->ws_v2;
-    net->a3sh = net->ws_a3sh; net->d3 = net->ws_d3; net->v3 = net->ws_v3;
+    net->a3sh = net->ws_a3sh; net->d3 = net->ws_d3; net->m3 = net->ws_m3;
     net->sraw = net->ws_sraw; net->a2sh = net->ws_a2sh; net->d2s = net->ws_d2s; net->v2s = net->ws_v2s; net->ulist = net->ws_ulist;
     if (slot < 0 || !net->keep) return;
     const size_t c = net->chunk;
@@ -389,7 +391,7 @@ static void bind_activations(grl_net *net, long slot) {
     if (net->shared_trunk) {
         net->a3sh = b; b += (c / 10) * 3136;
         net->d3 = b; b += c * 1600;
-        net->v3 = b; b += c * 1600;
+        net->m3 = reinterpret_cast<unsigned long long *>(b); b += c * 50;
     } else {
         net->a3 = b; b += c * 3136;
     }
@@ -496,9 +498,9 @@ static int alloc_lane_forward(grl_net *n) {
     A(&n->sraw, (c / 10) * 12800); A(&n->a1sh, (c / 10) * 12800); A(&n->z2sh, (c / 10) * 5184);
     A(&n->a2sh, (c / 10) * 5184); A(&n->d2s, c * 9 * 64); A(&n->v2s, c * 9 * 64); A(&n->z3sh, (c / 10) * 3136);
     if (rc == GRL_OK) rc = nalloc(n, &n->ulist, c * 9);
-    A(&n->a3sh, (c / 10) * 3136); A(&n->d3, c * 1600); A(&n->v3, c * 1600); A(&n->ysh, (c / 10) * 512);
+    A(&n->a3sh, (c / 10) * 3136); A(&n->d3, c * 1600); if (rc == GRL_OK) rc = nalloc(n, &n->m3, c * 25); A(&n->ysh, (c / 10) * 512);
     n->ws_a3 = n->a3; n->ws_d1 = n->d1; n->ws_d2 = n->d2; n->ws_p1 = n->p1; n->ws_v1 = n->v1; n->ws_v2 = n->v2;
-    n->ws_a3sh = n->a3sh; n->ws_d3 = n->d3; n->ws_v3 = n->v3;
+    n->ws_a3sh = n->a3sh; n->ws_d3 = n->d3; n->ws_m3 = n->m3;
     n->ws_sraw = n->sraw; n->ws_a2sh = n->a2sh; n->ws_d2s = n->d2s; n->ws_v2s = n->v2s; n->ws_ulist = n->ulist;
     if (rc == GRL_OK) rc = nalloc(n, &n->perm, (size_t)n->ptiles * 256);
     if (rc == GRL_OK) rc = nalloc(n, &n->goffp, 16);
@@ -743,13 +745,13 @@ static int read_activation_impl(grl_net *n, const char *which, float *host, size
         return GRL_OK;
     }
     else if (w == "a2") { src = n->a2; per = 5184; }
-    else if (w == "a3" && n->shared_trunk) {     // likewise: a3sh with the agent's 5x5 patch replaced by v3
+    else if (w == "a3" && n->shared_trunk) {     // likewise: a3sh with the agent's 5x5 patch replaced by its own values
         size_t need_a = (size_t)n->last_n * 3136 * 4;
         if (bytes != need_a) return nfail(n, GRL_E_SIZE, "grl_net_read_activation: need " + std::to_string(need_a) + " bytes");
         if (n->last_n <= 0) return nfail(n, GRL_E_STATE, "grl_net_read_activation: no forward pass yet");
         float *tmp = nullptr;
         NET_HIP(n, hipMalloc((void **)&tmp, need_a));
-        hipLaunchKernelGGL(materialize_a3_kernel, dim3(n->last_n), dim3(256), 0, n->h->stream, n->a3sh, n->v3, n->org, tmp);
+        hipLaunchKernelGGL(materialize_a3_kernel, dim3(n->last_n), dim3(256), 0, n->h->stream, n->a3sh, n->d3, n->m3, n->org, tmp);
         hipError_t e1 = hipStreamSynchronize(n->h->stream), e2 = hipMemcpy(host, tmp, bytes, hipMemcpyDeviceToHost);
         (void)hipFree(tmp);
         if (e1 != hipSuccess || e2 != hipSuccess) return nfail(n, GRL_E_HIP, "grl_net_read_activation: expanding a3 failed");
