@@ -59,7 +59,8 @@ struct NetLane {
     float *sraw, *a1sh, *z2sh, *dz2, *gt;
     // shared conv3 gradients: per-env a2sh = relu(z2sh), DZ3; per (agent, slot <= 9 touched conv2 pixels): pixel id,
     // a2_a[u], a2_a[u] - a2sh[u], T3(dz3_a)[u], masked dz2_a[u]; tmpw3: correction GEMM output before the tap flip
-    float *a2sh, *d2s, *v2s, *gsl, *dza, *dz3sh, *tmpw3;
+    float *a2sh, *d2s, *gsl, *dza, *dz3sh, *tmpw3;
+    unsigned long long *m2s;   // ReLU mask of the touched conv2 pixels: one word of 64 channel bits per compact slot row
     float *at2, *dl2, *tt2, *tmpw2;   // conv2-level corrections as class-major GEMM operands (net_shared.inc)
     // shared conv3 forward: z3sh = conv3(a2sh) + b3 per env; the per-slot products (a2_a - a2sh)[u] . W3[tap]
     // (n*9 x 576) live in the a2 buffer, which has no other use in shared-trunk mode
@@ -80,7 +81,8 @@ struct NetLane {
     float *ro_mu;              // chunk-sized scratch of the gradient step (cmu csigma cvs dzh cact cadv cy)
     float *ws_a3, *ws_d1, *ws_d2, *ws_p1, *ws_v1, *ws_v2, *ws_a3sh, *ws_d3;   // chunk workspace (the default binding)
     unsigned long long *ws_m3;
-    float *ws_sraw, *ws_a2sh, *ws_d2s, *ws_v2s;
+    float *ws_sraw, *ws_a2sh, *ws_d2s;
+    unsigned long long *ws_m2s;
     signed char *ws_ulist;
     bool train_ready;
 };
@@ -370,12 +372,12 @@ __global__ void sample_actions_kernel(const float *__restrict__ mu, const float 
 
 // ------------------------------------------------------------------------------------------ forward pass of one chunk
 // floats kept per chunk slot: per-agent-trunk mode a3 + dense stack; shared mode a3sh (per env) + d3 + patch mask + dense stack,
-// and at level 2 also what the gradient step reads of the per-env trunk: sraw, a2sh (per env), d2s, v2s, ulist (per slot)
+// and at level 2 also what the gradient step reads of the per-env trunk: sraw, a2sh (per env), d2s, slot mask, ulist (per slot)
 static size_t keep_floats_per_slot(const grl_net *net, int level) {
     const size_t c = net->chunk, dense = 512 + 256 + 512 + 512 + 256;
     if (!net->shared_trunk) return c * (3136 + dense);
     size_t f = (c / 10) * 3136 + c * (1600 + 50 + dense);      // m3: 25 x 8 bytes per sample
-    if (level >= 2) f += (c / 10) * (12800 + 5184) + c * (576 + 576) + ((c * 9 + 3) / 4 + 3) / 4 * 4;      // stays a multiple of 16 bytes
+    if (level >= 2) f += (c / 10) * (12800 + 5184) + c * (576 + 18) + ((c * 9 + 3) / 4 + 3) / 4 * 4;      // stays a multiple of 16 bytes
     return f;
 }
 
@@ -384,7 +386,7 @@ static size_t keep_floats_per_slot(const grl_net *net, int level) {
 static void bind_activations(grl_net *net, long slot) {
     net->a3 = net->ws_a3; net->d1 = net->ws_d1; net->d2 = net->ws_d2; net->p1 = net->ws_p1; net->v1 = net->ws_v1; net->v2 = net->ws_v2;
     net->a3sh = net->ws_a3sh; net->d3 = net->ws_d3; net->m3 = net->ws_m3;
-    net->sraw = net->ws_sraw; net->a2sh = net->ws_a2sh; net->d2s = net->ws_d2s; net->v2s = net->ws_v2s; net->ulist = net->ws_ulist;
+    net->sraw = net->ws_sraw; net->a2sh = net->ws_a2sh; net->d2s = net->ws_d2s; net->m2s = net->ws_m2s; net->ulist = net->ws_ulist;
     if (slot < 0 || !net->keep) return;
     const size_t c = net->chunk;
     float *b = net->keep + (size_t)slot * keep_floats_per_slot(net, net->keep_level);
@@ -404,7 +406,7 @@ static void bind_activations(grl_net *net, long slot) {
         net->sraw = b; b += (c / 10) * 12800;
         net->a2sh = b; b += (c / 10) * 5184;
         net->d2s = b; b += c * 576;
-        net->v2s = b; b += c * 576;
+        net->m2s = reinterpret_cast<unsigned long long *>(b); b += c * 18;      // 9 words per sample
         net->ulist = reinterpret_cast<signed char *>(b);
     }
 }
@@ -496,12 +498,12 @@ static int alloc_lane_forward(grl_net *n) {
     A(&n->a2, c * 5184); A(&n->d1, c * 512); A(&n->d2, c * 256); A(&n->p1, c * 512); A(&n->v1, c * 512); A(&n->v2, c * 256);
     if (!n->shared_trunk) { A(&n->a1, c * 12800); A(&n->a3, c * 3136); }       // per-agent tensors the shared evaluation never forms
     A(&n->sraw, (c / 10) * 12800); A(&n->a1sh, (c / 10) * 12800); A(&n->z2sh, (c / 10) * 5184);
-    A(&n->a2sh, (c / 10) * 5184); A(&n->d2s, c * 9 * 64); A(&n->v2s, c * 9 * 64); A(&n->z3sh, (c / 10) * 3136);
+    A(&n->a2sh, (c / 10) * 5184); A(&n->d2s, c * 9 * 64); if (rc == GRL_OK) rc = nalloc(n, &n->m2s, c * 9); A(&n->z3sh, (c / 10) * 3136);
     if (rc == GRL_OK) rc = nalloc(n, &n->ulist, c * 9);
     A(&n->a3sh, (c / 10) * 3136); A(&n->d3, c * 1600); if (rc == GRL_OK) rc = nalloc(n, &n->m3, c * 25); A(&n->ysh, (c / 10) * 512);
     n->ws_a3 = n->a3; n->ws_d1 = n->d1; n->ws_d2 = n->d2; n->ws_p1 = n->p1; n->ws_v1 = n->v1; n->ws_v2 = n->v2;
     n->ws_a3sh = n->a3sh; n->ws_d3 = n->d3; n->ws_m3 = n->m3;
-    n->ws_sraw = n->sraw; n->ws_a2sh = n->a2sh; n->ws_d2s = n->d2s; n->ws_v2s = n->v2s; n->ws_ulist = n->ulist;
+    n->ws_sraw = n->sraw; n->ws_a2sh = n->a2sh; n->ws_d2s = n->d2s; n->ws_m2s = n->m2s; n->ws_ulist = n->ulist;
     if (rc == GRL_OK) rc = nalloc(n, &n->perm, (size_t)n->ptiles * 256);
     if (rc == GRL_OK) rc = nalloc(n, &n->goffp, 16);
     if (rc == GRL_OK) rc = nalloc(n, &n->sbeg, n->pslices);
@@ -738,7 +740,7 @@ static int read_activation_impl(grl_net *n, const char *which, float *host, size
         if (n->last_n <= 0) return nfail(n, GRL_E_STATE, "grl_net_read_activation: no forward pass yet");
         float *tmp = nullptr;
         NET_HIP(n, hipMalloc((void **)&tmp, need_a));
-        hipLaunchKernelGGL(materialize_a2_kernel, dim3(n->last_n), dim3(256), 0, n->h->stream, n->a2sh, n->v2s, n->ulist, n->sbase, tmp);
+        hipLaunchKernelGGL(materialize_a2_kernel, dim3(n->last_n), dim3(256), 0, n->h->stream, n->a2sh, n->d2s, n->m2s, n->ulist, n->sbase, tmp);
         hipError_t e1 = hipStreamSynchronize(n->h->stream), e2 = hipMemcpy(host, tmp, bytes, hipMemcpyDeviceToHost);
         (void)hipFree(tmp);
         if (e1 != hipSuccess || e2 != hipSuccess) return nfail(n, GRL_E_HIP, "grl_net_read_activation: expanding a2 failed");
