@@ -56,7 +56,7 @@ struct NetLane {
     // gradients of activations (chunk)
     float *ga1, *ga2, *ga3, *gd1, *gd2, *gp1, *gv1, *gv2;
     // shared-trunk evaluation of conv1/conv2 (net_shared.inc): per-ENV tensors
-    float *sraw, *a1sh, *z2sh, *dz2, *gt;
+    float *sraw, *z2sh, *dz2, *gt;
     // shared conv3 gradients: per-env a2sh = relu(z2sh), DZ3; per (agent, slot <= 9 touched conv2 pixels): pixel id,
     // a2_a[u], a2_a[u] - a2sh[u], T3(dz3_a)[u], masked dz2_a[u]; tmpw3: correction GEMM output before the tap flip
     float *a2sh, *d2s, *gsl, *dza, *dz3sh, *tmpw3;
@@ -247,7 +247,7 @@ static void refresh_transposes(grl_net *net) {
 __global__ __launch_bounds__(256) void conv1_sparse_kernel(const uint8_t *__restrict__ lbins, const uint8_t *__restrict__ abins,
                                                            const uint8_t *__restrict__ pos, const float *__restrict__ w1,
                                                            const float *__restrict__ b1, float *__restrict__ a1, int G,
-                                                           float *__restrict__ sraw, float *__restrict__ a1sh) {
+                                                           float *__restrict__ sraw) {
     __shared__ unsigned int cnt[2][7056 / 4 + 4];   // 84x84 byte counters per channel, packed 4 per word
     __shared__ float S[400 * 32];                    // pre-activation shared by the env's 10 agents
     const int env = blockIdx.x, tid = threadIdx.x;
@@ -289,14 +289,10 @@ __global__ __launch_bounds__(256) void conv1_sparse_kernel(const uint8_t *__rest
         for (int co = 0; co < 32; ++co) S[pix * 32 + co] = acc[co];
     }
     __syncthreads();
-    if (sraw) {   // shared-trunk mode (net_shared.inc): one pre-activation and one relu image per ENV, no per-agent copies
-        float4 *o0 = reinterpret_cast<float4 *>(sraw + (size_t)env * 12800), *o1 = reinterpret_cast<float4 *>(a1sh + (size_t)env * 12800);
-        for (int i = tid; i < 3200; i += 256) {
-            float4 v = reinterpret_cast<const float4 *>(S)[i];
-            o0[i] = v;
-            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-            o1[i] = v;
-        }
+    if (sraw) {   // shared-trunk mode (net_shared.inc): one pre-activation image per ENV, no per-agent copies
+        // only the pre-activation is stored: conv2's gathers apply the ReLU while loading (GatherConv2Relu)
+        float4 *o0 = reinterpret_cast<float4 *>(sraw + (size_t)env * 12800);
+        for (int i = tid; i < 3200; i += 256) o0[i] = reinterpret_cast<const float4 *>(S)[i];
         return;
     }
     for (int a = 0; a < 10; ++a) {
@@ -432,7 +428,7 @@ static int forward_chunk(grl_net *net, const uint8_t *lb, const uint8_t *ab, con
     } else {
     net->prof_tag_cur = PT_PER_AGENT;
     hipLaunchKernelGGL(conv1_sparse_kernel, dim3(nenv), dim3(256), 0, st, lb, ab, pos, P + ConvOffsets::c1w, P + ConvOffsets::c1b,
-                       net->a1, net->h->cfg.grid_size, (float *)nullptr, (float *)nullptr);
+                       net->a1, net->h->cfg.grid_size, (float *)nullptr);
     {
         GatherConv2 g{net->a1, n * 81};
         EpiBiasAct e{net->a2, 64, P + ConvOffsets::c2b, ACT_RELU};
@@ -497,7 +493,7 @@ static int alloc_lane_forward(grl_net *n) {
     A(&n->grads, ConvOffsets::total);
     A(&n->a2, c * 5184); A(&n->d1, c * 512); A(&n->d2, c * 256); A(&n->p1, c * 512); A(&n->v1, c * 512); A(&n->v2, c * 256);
     if (!n->shared_trunk) { A(&n->a1, c * 12800); A(&n->a3, c * 3136); }       // per-agent tensors the shared evaluation never forms
-    A(&n->sraw, (c / 10) * 12800); A(&n->a1sh, (c / 10) * 12800); A(&n->z2sh, (c / 10) * 5184);
+    A(&n->sraw, (c / 10) * 12800); A(&n->z2sh, (c / 10) * 5184);
     A(&n->a2sh, (c / 10) * 5184); A(&n->d2s, c * 9 * 64); if (rc == GRL_OK) rc = nalloc(n, &n->m2s, c * 9); A(&n->z3sh, (c / 10) * 3136);
     if (rc == GRL_OK) rc = nalloc(n, &n->ulist, c * 9);
     A(&n->a3sh, (c / 10) * 3136); A(&n->d3, c * 1600); if (rc == GRL_OK) rc = nalloc(n, &n->m3, c * 25); A(&n->ysh, (c / 10) * 512);
@@ -731,7 +727,11 @@ static int read_activation_impl(grl_net *n, const char *which, float *host, size
         size_t need_e = (size_t)(n->last_n / 10) * 12800 * 4;
         if (bytes != need_e) return nfail(n, GRL_E_SIZE, "grl_net_read_activation: need " + std::to_string(need_e) + " bytes");
         NET_HIP(n, hipStreamSynchronize(n->h->stream));
-        NET_HIP(n, hipMemcpy(host, w == "a1sh" ? n->a1sh : n->sraw, bytes, hipMemcpyDeviceToHost));
+        NET_HIP(n, hipMemcpy(host, n->sraw, bytes, hipMemcpyDeviceToHost));
+        if (w == "a1sh") {     // relu(sraw): not materialised on the device
+            float *hp = static_cast<float *>(host);
+            for (size_t i = 0; i < need_e / 4; ++i) hp[i] = hp[i] > 0.f ? hp[i] : 0.f;
+        }
         return GRL_OK;
     }
     else if (w == "a2" && n->shared_trunk) {     // not materialised in shared-trunk mode: expand it on demand (debug/test access)

@@ -39,7 +39,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // Row r of the (virtual) operand = output pixel (n, qy, qx); reduction index k = ((ty*P + tx)*C + c)
 // reads src[n][iy0+ty][ix0+tx][c] with (iy0, ix0) = (qy*SY + OY0, qx*SX + OX0) in an NHWC tensor
 // [n][H][W][C].  CHECK=true zero-fills taps outside the image (transposed convolutions).
-// RELU=true: the operand is relu(src) (gemm_tn only: conv2's weight gradient reads a1sh = relu(sraw) from the pre-activation)
+// RELU=true: the operand is relu(src): conv2's forward and weight gradient read a1sh = relu(sraw) straight from the pre-activation
 template <int QH, int QW, int SY, int SX, int OY0, int OX0, int S, int P, int C, int H, int W, bool CHECK, bool RELU = false>
 struct ConvGather {
     static constexpr int kPPS = QH * QW;
@@ -533,6 +533,7 @@ __global__ __launch_bounds__(256, 2) void gemm_rowk(AG ag, const float *__restri
             const bool v = (vmask >> i) & 1u;                                                              \
             float4 t4 = ra[i];                                                                             \
             t4.x = v ? t4.x : 0.f; t4.y = v ? t4.y : 0.f; t4.z = v ? t4.z : 0.f; t4.w = v ? t4.w : 0.f;    \
+            if (AG::kRelu) { t4.x = fmaxf(t4.x, 0.f); t4.y = fmaxf(t4.y, 0.f); t4.z = fmaxf(t4.z, 0.f); t4.w = fmaxf(t4.w, 0.f); } \
             GRL_STORE_PLANES(As, (trow + 32 * i) * LDH + wo, t4)                                           \
         }                                                                                                  \
         GRL_STORE_PLANES(Bs, trow * LDH + wo, rb0)                                                         \
