@@ -318,8 +318,12 @@ struct PatchRows {
 //   elem_aux(r, c, ra)    per output element: ReLU mask source, per-env term, bias
 //   store(r, c, v, ra, ea)
 enum { ACT_NONE = 0, ACT_RELU = 1 };
+// kColSum = true: the epilogue also wants the column sums of what it stores (bias gradient of the layer whose dY it
+// produces) and defines value(v, ea) and csum
 
-struct EpiBiasAct {   // C[r][c] = act(v + bias[c])
+
+struct EpiBiasAct {
+    static constexpr bool kColSum = false;   // C[r][c] = act(v + bias[c])
     float *C;
     int ldc;
     const float *bias;
@@ -333,7 +337,8 @@ struct EpiBiasAct {   // C[r][c] = act(v + bias[c])
     }
 };
 
-struct EpiPatchFwd {   // sorted row -> sample m: out[m][c] = relu(v + ysh[env(m)][c]) (ysh = per-env part incl. bias)
+struct EpiPatchFwd {
+    static constexpr bool kColSum = false;   // sorted row -> sample m: out[m][c] = relu(v + ysh[env(m)][c]) (ysh = per-env part incl. bias)
     float *out;
     const float *ysh;
     const int *perm;
@@ -345,7 +350,8 @@ struct EpiPatchFwd {   // sorted row -> sample m: out[m][c] = relu(v + ysh[env(m
     }
 };
 
-struct EpiPermStore {   // sorted row -> sample m: out[m][c] = v
+struct EpiPermStore {
+    static constexpr bool kColSum = false;   // sorted row -> sample m: out[m][c] = v
     float *out;
     const int *perm;
     int ld;
@@ -356,7 +362,8 @@ struct EpiPermStore {   // sorted row -> sample m: out[m][c] = v
     }
 };
 
-struct EpiGrad {   // dX[r][c] = v * (fwd[r][c] > 0): data gradient with the ReLU mask of the forward tensor fused
+struct EpiGrad {
+    static constexpr bool kColSum = false;   // dX[r][c] = v * (fwd[r][c] > 0): data gradient with the ReLU mask of the forward tensor fused
     float *dX;
     int ld;
     const float *fwd;   // forward activation of the same tensor (post-ReLU)
@@ -365,7 +372,23 @@ struct EpiGrad {   // dX[r][c] = v * (fwd[r][c] > 0): data gradient with the ReL
     __device__ __forceinline__ void store(int r, int c, float v, int, float ea) const { dX[(long)r * ld + c] = ea > 0.f ? v : 0.f; }
 };
 
-struct EpiStore {   // dX[r][c] = v
+// EpiGrad that also writes, per 64-row wave tile, the column sums of the masked gradient it stores: csum[wave tile][N].
+// Summed over the wave tiles (slab_reduce_narrow_kernel) this is the bias gradient of the layer below -- dY never has
+// to be read again for it.
+struct EpiGradSum {
+    static constexpr bool kColSum = true;
+    float *dX;
+    int ld;
+    const float *fwd;
+    float *csum;
+    __device__ __forceinline__ int row_aux(int) const { return 0; }
+    __device__ __forceinline__ float elem_aux(int r, int c, int) const { return fwd[(long)r * ld + c]; }
+    __device__ __forceinline__ float value(float v, float ea) const { return ea > 0.f ? v : 0.f; }
+    __device__ __forceinline__ void store(int r, int c, float v, int, float ea) const { dX[(long)r * ld + c] = value(v, ea); }
+};
+
+struct EpiStore {
+    static constexpr bool kColSum = false;   // dX[r][c] = v
     float *dX;
     int ld;
     __device__ __forceinline__ int row_aux(int) const { return 0; }
@@ -373,7 +396,8 @@ struct EpiStore {   // dX[r][c] = v
     __device__ __forceinline__ void store(int r, int c, float v, int, float) const { dX[(long)r * ld + c] = v; }
 };
 
-struct EpiGradPM {   // pixel-major rows (r = q*nsamp + n) -> dX[n][q][c], ReLU mask of the forward tensor fused
+struct EpiGradPM {
+    static constexpr bool kColSum = false;   // pixel-major rows (r = q*nsamp + n) -> dX[n][q][c], ReLU mask of the forward tensor fused
     float *dX;
     const float *fwd;
     int nsamp, pps, ld;
@@ -390,6 +414,7 @@ struct EpiGradPM {   // pixel-major rows (r = q*nsamp + n) -> dX[n][q][c], ReLU 
 // -> pixel (2yh+py, 2xh+px), channel c of the [n][20][20][32] tensor
 template <bool MASK>
 struct EpiGradStride2 {
+    static constexpr bool kColSum = false;
     float *dX;
     const float *fwd;     // MASK = false: raw transposed convolution (shared-trunk mode), fwd unused
     __device__ __forceinline__ int row_aux(int r) const {      // offset of pixel (2yh, 2xh) (< 2^31: 40 960 x 12 800)
@@ -616,6 +641,21 @@ __global__ __launch_bounds__(256, 2) void gemm_rowk(AG ag, const float *__restri
                 const int row = erow + a * 16 + r, col = ecol + b * 16;
                 if (row < M && col < N) epi.store(row, col, acc[a][b][r], rax[a][r], eax[a][b][r]);
             }
+    if constexpr (Epi::kColSum) {      // column sums of the stored values over this wave's rows, in a fixed order
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            float sum = 0.f;
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (erow + a * 16 + r < M) sum += epi.value(acc[a][b][r], eax[a][b][r]);
+            sum += __shfl_xor(sum, 16);
+            sum += __shfl_xor(sum, 32);
+            const int col = ecol + b * 16;
+            if (kg == 0 && col < N) epi.csum[(long)(by * WGM + wm) * N + col] = sum;
+        }
+    }
 #undef GRL_LOAD_TILE
 #undef GRL_STORE_TILE
 #undef GRL_STORE_PLANES
