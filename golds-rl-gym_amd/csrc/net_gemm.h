@@ -412,11 +412,15 @@ struct EpiGradPM {
 // data gradient of conv2: the four pixel-parity classes (py,px) read the SAME 2x2 source taps and differ
 // only in their kernel, so they are the N = 4*32 columns of one GEMM: row (n, yh, xh), column cls*32 + c
 // -> pixel (2yh+py, 2xh+px), channel c of the [n][20][20][32] tensor
-template <bool MASK>
+// MASK: the ReLU mask of the forward tensor `fwd` (same layout; a pre-activation serves as well: relu'(s) = s > 0) is fused.
+// SUM: the epilogue also writes the per-wave-tile column sums of what it stores (csum[wave tile][128]; folded over the four
+// classes they are conv1's bias gradient).
+template <bool MASK, bool SUM = false>
 struct EpiGradStride2 {
-    static constexpr bool kColSum = false;
+    static constexpr bool kColSum = SUM;
     float *dX;
-    const float *fwd;     // MASK = false: raw transposed convolution (shared-trunk mode), fwd unused
+    const float *fwd;     // MASK = false: raw transposed convolution, fwd unused
+    float *csum;
     __device__ __forceinline__ int row_aux(int r) const {      // offset of pixel (2yh, 2xh) (< 2^31: 40 960 x 12 800)
         int n = r / 100, q = r - n * 100;
         int yh = q / 10, xh = q - yh * 10;
@@ -427,10 +431,28 @@ struct EpiGradStride2 {
         return ((cls >> 1) * 20 + (cls & 1)) * 32 + c;
     }
     __device__ __forceinline__ float elem_aux(int, int c, int base) const { return MASK ? fwd[(long)base + col_off(c)] : 0.f; }
-    __device__ __forceinline__ void store(int, int c, float v, int base, float ea) const {
-        dX[(long)base + col_off(c)] = (!MASK || ea > 0.f) ? v : 0.f;
-    }
+    __device__ __forceinline__ float value(float v, float ea) const { return (!MASK || ea > 0.f) ? v : 0.f; }
+    __device__ __forceinline__ void store(int, int c, float v, int base, float ea) const { dX[(long)base + col_off(c)] = value(v, ea); }
 };
+
+// c1b[c] += sum over wave tiles and the four classes of csum[tile][cls * 32 + c] (fixed order)
+__global__ __launch_bounds__(256) void fold_class_sums_kernel(const float *__restrict__ csum, int parts, float *__restrict__ dst) {
+    __shared__ float red[256];
+    const int c = threadIdx.x & 31, k = threadIdx.x >> 5;      // 8 partial sums per channel
+    float s = 0.f;
+    for (int p = k; p < parts; p += 8) {
+        const float *row = csum + (long)p * 128 + c;
+        s += (row[0] + row[32]) + (row[64] + row[96]);
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t += red[j * 32 + threadIdx.x];
+        dst[threadIdx.x] += t;
+    }
+}
 
 // ---------------------------------------------------------------------------- fp32 operands on the bf16 matrix pipe
 // x = h + m + l exactly: h = the upper 16 bits of x (truncation to bf16), m = the upper 16 bits of x - h, l = x - h - m
