@@ -16,7 +16,11 @@ Gaussian policy: the env/observation/returns kernels alone).
 
 Envs are independent, so N GPUs shard the env batch (global env ids key the generators; results do
 not depend on N); the only collective is one all-reduce of the 2.2M-float gradient per update.
-scaling = weak (32 768 envs per GPU).
+scaling = weak (32 768 envs per GPU = BASELINE configs[3] at N=8); for N>1 the line also carries a
+`strong_scaling` point (32 768 envs in total, the shape BASELINE's target is quoted on).
+
+N>1 without a launcher: `python bench.py --gpus N` starts N fresh rank processes itself (before anything
+touches the GPU) and relays rank 0's line; under torch.distributed.run WORLD_SIZE must equal --gpus.
 """
 import argparse
 import json
@@ -42,6 +46,7 @@ MFMA_BF16_PEAK_TFLOPS = 2516.6       # MI355X_MICROARCH.md: dense bf16 matrix pe
 # (net_gemm.h), so the matrix pipe bounds the fp32-equivalent rate at 2516.6 / 6
 BF16_PRODUCTS_PER_FP32 = 6
 MFMA_X6_PEAK_TFLOPS = MFMA_BF16_PEAK_TFLOPS / BF16_PRODUCTS_PER_FP32
+GEMM_TRAFFIC_FILE = "r01_gemm_traffic.json"   # PMC pass of the GEMM kernels (tools/run_prof.sh); refreshed per round
 
 
 def parse():
@@ -60,6 +65,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the rollout_only / env_only side measurements")
     ap.add_argument("--cpu-sample-envs", type=int, default=2048)
+    ap.add_argument("--no-strong", action="store_true", help="N>1: skip the strong-scaling point (32 768 envs in total)")
+    ap.add_argument("--no-flat-configs", action="store_true", help="skip the Solow-4096 / TradeAR1-16 side blocks (configs 2 and 5)")
+    ap.add_argument("--exchange", default="rccl", choices=["rccl", "gloo"], help="gradient exchange to try first for N>1")
     return ap.parse_args()
 
 
@@ -177,94 +185,114 @@ def timed(run, wait, steps):
     return time.perf_counter() - t0
 
 
-def main():
-    args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if "GRL_BENCH_FORCE_DEVICE" in os.environ:      # rehearsal of the N > 1 control flow on a one-GPU box only
-        local_rank = int(os.environ["GRL_BENCH_FORCE_DEVICE"])
-    dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist   # rendezvous / barrier / max only; the data path never touches torch
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+def flat_config_block(kind, E, T, device_id, steps=10):
+    """BASELINE configs[1] (Solow-v0, 4 096 envs) / the per-GPU share of configs[4] (TradeAR1 n=16, 65 536 envs / 8 GPUs = 8 192)
+    with FlatPolicyVNetwork (GRU(32) + MLP): device-resident T-step PAAC rollout (one hipGraph) + gradient step, timed here so the
+    numbers are driver-visible.  These shapes are LAUNCH/LATENCY bound: a step moves E x 53 B (Solow) / E x 481 B
+    (TradeAR1-16) of env state and ~45 kMAC per sample through ~40 dependent stages; a bandwidth fraction would be meaningless, so
+    the block states the per-update time, the number of dependent launches and the bytes for scale."""
+    from goldsrl import _ffi
+    from goldsrl import rollout as R
+    if kind == "solow":
+        eng = _ffi.Engine(_ffi.ENV_SOLOW, E, device_id=device_id, seed=1692)
+        bytes_per_env_step, what = 53, "Solow-v0 (p=q=1), %d envs, T=%d, FlatPolicyVNetwork (GRU(32) over 5 rows + MLP)" % (E, T)
+    else:
+        eng = _ffi.Engine(_ffi.ENV_TRADE, E, device_id=device_id, seed=1692, n_assets=16, rnn_length=20)
+        bytes_per_env_step, what = 481, "TradeAR1-v0 n=16, %d envs (65 536 / 8 GPUs), T=%d, GRU(32) policy over 20 rows of 33" % (E, T)
+    eng.reset()
+    roll = R.FlatPolicyRollout(eng, T)
+    out = {"workload": what}
+    for label, train in (("rollout_only", False), ("value", True)):
+        roll.train = train
+        roll.run(); eng.wait()
+        dt = timed(roll.run, eng.wait, steps) / steps
+        out[label] = E * T / dt
+        out["ms_per_update" if train else "ms_per_rollout"] = dt * 1e3
+    out.update({"unit": "env-steps/s", "steps": steps, "dtype": "f32",
+                "bound": "launch/latency",
+                "dependent_launches_per_update": T * 4 + 2 + 6,      # T x (forward, sample, env step, mask) in one graph + bootstrap/returns + fwd/bwd/reduce/norm/finalize/adam
+                "env_bytes_per_update": E * T * bytes_per_env_step,
+                "note": "value = rollout + loss/backward/clip/Adam; %d KB of env traffic per step against ~%d us per step: not "
+                        "bandwidth bound at this size" % (E * bytes_per_env_step // 1024, int(out["ms_per_rollout"] * 1e3 / (T + 1)))})
+    roll.net.close(); eng.close()
+    return out
 
+
+def measure_swarm(args, ranks, E, T, want_roofline, label):
+    """One Swarm PAAC workload on this rank's shard of E envs: warmup, K timed updates (barrier + device sync on both sides,
+    max over ranks), then (rank 0, single-stream extra update) the per-GEMM HIP-event pass for the roofline."""
     from goldsrl import _ffi, sharding
-    E, T = args.envs, args.T
+    from goldsrl import distributed as D
+    rank, world = ranks.rank, ranks.world
     off = sharding.env_id_offset(rank, E)
     flags = _ffi.F_SWARM_FAST_MATH if args.fast_math else 0
-    eng = _ffi.Engine(_ffi.ENV_SWARM, E, device_id=local_rank, seed=1692, env_id_offset=off, flags=flags)
+    device = int(os.environ["GRL_BENCH_FORCE_DEVICE"]) if "GRL_BENCH_FORCE_DEVICE" in os.environ else ranks.local_rank
+    eng = _ffi.Engine(_ffi.ENV_SWARM, E, device_id=device, seed=1692, env_id_offset=off, flags=flags)
     eng.reset()
-
-    net = None
-    exchange = "none"
+    net, exchange = None, "none"
     if args.policy == "conv":
         from goldsrl import rollout as R
         roll = R.ConvPolicyRollout(eng, T, train=not args.no_train, reserved=4 if args.single_stream else 0)
         net = roll.net
-        if world > 1:
-            # one RCCL communicator over the ranks (xGMI); if any rank cannot form it, every rank falls back to summing the
-            # 8.8 MB gradient on the host through gloo -- slower, same mathematics (parameters stay replicated)
-            ok = 1
-            try:
-                uid = net.comm_unique_id() if rank == 0 else np.zeros(net.comm_unique_id().size, np.uint8)
-                t = torch.from_numpy(uid)
-                dist.broadcast(t, src=0)
-                net.comm_init(t.numpy(), rank, world)
-            except Exception as e:       # noqa: BLE001 -- any failure means "no device communicator"
-                sys.stderr.write("rank %d: RCCL communicator unavailable (%s)\n" % (rank, e))
-                ok = 0
-            flag = torch.tensor([ok], dtype=torch.int32)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag[0]) == 1:
-                net.comm_broadcast_params(0)
-                exchange = "rccl"
-            else:
-                if ok:
-                    net.comm_destroy()
-                pt = torch.from_numpy(net.get_params())
-                dist.broadcast(pt, src=0)
-                net.set_params(pt.numpy())
-
-                def host_allreduce(g):
-                    tg = torch.from_numpy(np.ascontiguousarray(g))
-                    dist.all_reduce(tg, op=dist.ReduceOp.SUM)
-                    return tg.numpy(), world
-                roll.host_allreduce = host_allreduce
-                exchange = "gloo-host-fallback"
+        exchange = D.attach_gradient_exchange(roll, ranks, prefer=args.exchange)
     else:
         roll = RandomPolicyRollout(eng, T)
 
     def barrier():
         eng.wait()
-        if dist is not None:
-            dist.barrier()
+        ranks.barrier()
 
     for _ in range(args.warmup):
         roll.run()
     barrier()
     eng.profile_enable(True)       # HIP events around the env step kernel only (it runs alone on the handle's stream)
     elapsed = timed(roll.run, eng.wait, args.steps)
-    if dist is not None:
-        dist.barrier()
+    ranks.barrier()
+    elapsed = ranks.max(elapsed)
     env_launches, env_kernel_ms = eng.profile_read()
     eng.profile_enable(False)
+    res = {"eng": eng, "roll": roll, "net": net, "exchange": exchange, "elapsed": elapsed, "E": E,
+           "env_launches": env_launches, "env_kernel_ms": env_kernel_ms, "gemm": None, "gemm_step_s": None, "gemm_tags": {}}
     # GEMM roofline: one more update of the same workload with a HIP event pair around every gemm_rowk / gemm_tn launch.
     # Per-launch events need the launches serialised, so this pass runs on one stream; the timed region above alternates
     # independent chunks between four streams, where kernels of different chunks overlap and have no clean duration.
-    gemm, gemm_step_s, gemm_tags = None, None, {}
-    if net is not None:
+    if net is not None and want_roofline:
         net.profile_enable(True)
-        gemm_step_s = timed(roll.run, eng.wait, 1)
-        gemm = net.profile_read()
-        gemm_tags = net.profile_read_tags()
+        res["gemm_step_s"] = timed(roll.run, eng.wait, 1)      # every rank runs it: the update contains the collective
+        res["gemm"] = net.profile_read()
+        res["gemm_tags"] = net.profile_read_tags()
         net.profile_enable(False)
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt[0])
+        ranks.barrier()
+    return res
+
+
+def main():
+    args = parse()
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # No launcher: this parent has not imported goldsrl or touched HIP; it starts N fresh rank processes and only waits.
+        # Rank 0 prints the JSON line on the inherited stdout.  Any failing rank stops the job with a non-zero exit code.
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("_grl_distributed", os.path.join(ROOT, "golds-rl-gym_amd", "goldsrl", "distributed.py"))
+        D = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(D)
+        rc = D.spawn_local_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus)
+        if rc != 0:
+            sys.stderr.write("bench.py: a rank failed (exit code %d); no result line\n" % rc)
+        sys.exit(rc)
+
+    from goldsrl import distributed as D
+    ranks = D.Ranks()
+    if ranks.world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d: refusing to print a line for a job of another size" % (args.gpus, ranks.world))
+    ranks.init()
+    rank, world = ranks.rank, ranks.world
+    E, T = args.envs, args.T
+
+    m = measure_swarm(args, ranks, E, T, want_roofline=True, label="weak")
+    eng, roll, net, exchange, elapsed = m["eng"], m["roll"], m["net"], m["exchange"], m["elapsed"]
+    env_launches, env_kernel_ms, gemm, gemm_step_s, gemm_tags = m["env_launches"], m["env_kernel_ms"], m["gemm"], m["gemm_step_s"], m["gemm_tags"]
 
     extras = {}
     if not args.no_extras and args.policy == "conv" and world == 1:
@@ -280,6 +308,27 @@ def main():
         dt = timed(rr.run, eng.wait, 5)
         extras["env_only"] = {"value": E * T * 5 / dt, "unit": "env-steps/s", "steps": 5,
                               "what": "random Gaussian policy: action draw + norm clip + env step + auto-reset + process_state + returns"}
+    last_stats = getattr(roll, "last_stats", None)
+    # release the 32 768-env job (rollout-resident activations) before the side measurements
+    if net is not None:
+        net.close()
+    eng.close()
+
+    if world > 1 and not args.no_strong and args.policy == "conv" and E % world == 0:
+        # strong scaling: BASELINE's target shape, 32 768 envs IN TOTAL, E / world per rank
+        sargs = argparse.Namespace(**vars(args))
+        sargs.warmup, sargs.steps = 2, max(3, min(args.steps, 10))
+        sm = measure_swarm(sargs, ranks, E // world, T, want_roofline=False, label="strong")
+        extras["strong_scaling"] = {"value": E * T * sargs.steps / sm["elapsed"], "unit": "env-steps/s", "envs_total": E,
+                                    "envs_per_gpu": E // world, "steps": sargs.steps, "ms_per_step": sm["elapsed"] / sargs.steps * 1e3,
+                                    "gradient_exchange": sm["exchange"], "scaling": "strong"}
+        if sm["net"] is not None:
+            sm["net"].close()
+        sm["eng"].close()
+    if world == 1 and not args.no_flat_configs and not args.no_extras and args.policy == "conv":
+        device = int(os.environ.get("GRL_BENCH_FORCE_DEVICE", ranks.local_rank))
+        extras["solow_4096"] = flat_config_block("solow", 4096, T, device)
+        extras["trade16_gru_8192"] = flat_config_block("trade", 8192, T, device)
 
     if rank == 0:
         total_env_steps = world * E * T * args.steps
@@ -315,8 +364,9 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if args.policy == "conv" else "f64", "data": "synthetic",
             "config": {"workload": "Swarm-v0 84x84, %d envs per GPU, T=%d PAAC update, conv policy of train_paac_conv.py "
-                                   "(BASELINE configs[2])" % (E, T),
-                       "envs_per_gpu": E, "rollout_steps": T, "policy": args.policy, "train": args.policy == "conv" and not args.no_train,
+                                   "(BASELINE configs[2]%s)" % (E, T, "" if world == 1 else "; %d envs over %d GPUs = configs[3] at N=8" % (E * world, world)),
+                       "envs_per_gpu": E, "envs_total": E * world, "rollout_steps": T, "policy": args.policy,
+                       "train": args.policy == "conv" and not args.no_train,
                        "swarm_math": "fast" if args.fast_math else "exact", "env_state_dtype": "f64", "stages": stages,
                        "streams": 1 if (args.single_stream or args.policy != "conv") else 4,
                        "gradient_exchange": exchange},
@@ -325,7 +375,7 @@ def main():
             launches, ms, flops = gemm
             ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             gtraffic = None      # HBM bytes per GEMM launch from the committed PMC passes (same 40 960-sample chunks)
-            gpath = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")
+            gpath = os.path.join(ROOT, "profiles", GEMM_TRAFFIC_FILE)
             if os.path.exists(gpath):
                 with open(gpath) as f:
                     gtraffic = json.load(f).get("hbm_bytes_per_launch")
@@ -352,13 +402,14 @@ def main():
         else:
             out["roofline"] = env_roof
         out.update(extras)
-        if roll is not None and getattr(roll, "last_stats", None):
-            out["last_update_stats"] = roll.last_stats
+        if last_stats:
+            out["last_update_stats"] = last_stats
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample_envs, T)
         print(json.dumps(out))
-    if dist is not None:
-        dist.destroy_process_group()
+        sys.stdout.flush()
+    ranks.barrier()
+    ranks.close()
 
 
 if __name__ == "__main__":

@@ -15,6 +15,8 @@
 #include <string>
 #include <vector>
 
+#include <rccl/rccl.h>
+
 #include "../../include/goldsrl_flatnet.h"
 #include "common.h"
 #include "rng.h"
@@ -102,13 +104,15 @@ __global__ __launch_bounds__(256) void flat_sumsq_kernel(const float *__restrict
     if (threadIdx.x == 0) out[0] = red[0];
 }
 
+// grad_scale: 1/world after a sum over ranks (the loss is a mean over the WHOLE batch, policy_v_network.py:246-251); the norm and
+// the clip are those of grad_scale * grads, and the factor is folded into what Adam multiplies the stored gradient by
 __global__ void flat_finalize_kernel(const double *__restrict__ sumsq, const double *__restrict__ stats64, float inv_n, float inv_na,
-                                     float clip_norm, float *__restrict__ stats) {
+                                     float clip_norm, float grad_scale, float *__restrict__ stats) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    float norm = (float)sqrt(sumsq[0]);
+    float norm = (float)(sqrt(sumsq[0]) * (double)grad_scale);
     float pl = (float)(stats64[0] * (double)inv_na), cl = (float)(stats64[1] * (double)inv_n);
     stats[0] = pl; stats[1] = cl; stats[2] = pl + cl; stats[3] = norm;
-    stats[4] = clip_norm > 0.f ? clip_norm / fmaxf(norm, clip_norm) : 1.0f;      // tf.clip_by_global_norm
+    stats[4] = grad_scale * (clip_norm > 0.f ? clip_norm / fmaxf(norm, clip_norm) : 1.0f);      // tf.clip_by_global_norm
 }
 
 __global__ void flat_adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v, long n,
@@ -170,6 +174,9 @@ struct grl_fnet {
     uint32_t *d_counter;           // act_counter at the start of the rollout in flight
     hipGraphExec_t ro_graph;       // the T-step rollout captured once and replayed (launch-bound at 4 096 envs)
     int ro_graph_T;
+    int last_n;                    // samples of the last gradient pass (grl_fnet_apply_grads normalises the loss sums with it)
+    void *comm;                    // ncclComm_t (RCCL): one all-reduce of the flat gradient per rollout, or nullptr
+    int comm_world, comm_rank;
     std::vector<void *> allocs;
 };
 
@@ -210,9 +217,9 @@ static int launch_forward(grl_fnet *net, int n, const float *states, const float
     return GRL_OK;
 }
 
-// forward(save) + backward over n device-resident samples; grads <- mean-loss gradient; optional Adam
-static int train_device(grl_fnet *net, int n, const float *states, const float *hist, const float *actions, const float *adv, const float *y,
-                        float lr, int apply_update, float *stats_host, const int32_t *nhist = nullptr) {
+// forward(save) + backward over n device-resident samples; grads <- gradient of the mean loss over THESE n samples
+static int train_grads_device(grl_fnet *net, int n, const float *states, const float *hist, const float *actions, const float *adv,
+                              const float *y, const int32_t *nhist = nullptr) {
     hipStream_t st = net->h->stream;
     if (n > net->cfg.max_samples) return ffail(net, GRL_E_SIZE, "train: n exceeds max_samples of the net");
     int rc = launch_forward(net, n, states, hist, net->mu, net->sigma, net->vs, true, nhist);
@@ -226,9 +233,31 @@ static int train_device(grl_fnet *net, int n, const float *states, const float *
     hipLaunchKernelGGL(flat_backward_kernel, dim3(blocks), dim3(256), FLAT_LDS_BYTES, st, a);
     hipLaunchKernelGGL(flat_slab_reduce_kernel, dim3((unsigned)((net->off.total + 255) / 256)), dim3(256), 0, st, net->slab, blocks,
                        net->off.total, net->grads);
+    FNET_HIP(net, hipGetLastError());
+    net->last_n = n;
+    return GRL_OK;
+}
+
+// One all-reduce (sum, fp32) of the flat gradient per rollout over RCCL/xGMI, the rule of net_train.inc: every rank's
+// gradient is the mean over ITS T*E_local samples, the loss is a mean over the whole batch (policy_v_network.py:246-251), so the
+// sum is scaled by 1/world (folded into the clip factor); clip after the reduction, Adam replicated.
+static int fcomm_allreduce_grads(grl_fnet *net, float *grad_scale_out) {
+    *grad_scale_out = 1.0f;
+    if (!net->comm) return GRL_OK;
+    ncclResult_t r = ncclAllReduce(net->grads, net->grads, (size_t)net->off.total, ncclFloat, ncclSum, (ncclComm_t)net->comm, net->h->stream);
+    (void)hipGetLastError();   // RCCL probes may leave a stale HIP error on this thread
+    if (r != ncclSuccess) return ffail(net, GRL_E_COMM, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
+    *grad_scale_out = 1.0f / (float)net->comm_world;
+    return GRL_OK;
+}
+
+// global norm of grad_scale * grads, clip factor, loss statistics of the last gradient pass; then (apply_update) Adam
+static int train_apply_device(grl_fnet *net, float lr, int apply_update, float grad_scale, float *stats_host) {
+    hipStream_t st = net->h->stream;
+    const int n = net->last_n;
     hipLaunchKernelGGL(flat_sumsq_kernel, dim3(1), dim3(256), 0, st, net->grads, net->off.total, net->stats64 + 2);
     hipLaunchKernelGGL(flat_finalize_kernel, dim3(1), dim3(64), 0, st, net->stats64 + 2, net->stats64, 1.0f / (float)n,
-                       1.0f / ((float)n * (float)net->cfg.num_actions), net->cfg.clip_norm, net->stats);
+                       1.0f / ((float)n * (float)net->cfg.num_actions), net->cfg.clip_norm, grad_scale, net->stats);
     if (apply_update) {
         net->adam_t += 1;
         float lr_t = (float)((double)lr * sqrt(1.0 - pow(0.999, (double)net->adam_t)) / (1.0 - pow(0.9, (double)net->adam_t)));
@@ -243,6 +272,16 @@ static int train_device(grl_fnet *net, int n, const float *states, const float *
         stats_host[0] = s[2]; stats_host[1] = s[0]; stats_host[2] = s[1]; stats_host[3] = s[3];
     }
     return GRL_OK;
+}
+
+// gradient pass [+ all-reduce over ranks if a communicator is attached and the parameters are to be updated] + clip + Adam
+static int train_device(grl_fnet *net, int n, const float *states, const float *hist, const float *actions, const float *adv, const float *y,
+                        float lr, int apply_update, float *stats_host, const int32_t *nhist = nullptr) {
+    int rc = train_grads_device(net, n, states, hist, actions, adv, y, nhist);
+    if (rc) return rc;
+    float grad_scale = 1.0f;
+    if (apply_update && (rc = fcomm_allreduce_grads(net, &grad_scale))) return rc;
+    return train_apply_device(net, lr, apply_update, grad_scale, stats_host);
 }
 
 // the T-step actor loop as stream operations (captured into a graph by grl_fnet_rollout)
@@ -327,6 +366,7 @@ int grl_fnet_create(grl_handle *h, const grl_fnet_config *cfg, grl_fnet **out) {
     if (rc == GRL_OK) rc = falloc(n, &n->stats64, 8);
     if (rc == GRL_OK) rc = falloc(n, &n->d_counter, 4);
     n->ro_graph = nullptr; n->ro_graph_T = 0;
+    n->last_n = 0; n->comm = nullptr; n->comm_world = 1; n->comm_rank = 0;
     hipError_t e = hipSuccess;
     if (rc == GRL_OK) e = hipFuncSetAttribute((const void *)flat_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLAT_LDS_BYTES);
     if (rc == GRL_OK && e == hipSuccess)
@@ -347,6 +387,10 @@ int grl_fnet_destroy(grl_fnet *n) {
     hipSetDevice(n->h->cfg.device_id);
     hipStreamSynchronize(n->h->stream);
     if (n->ro_graph) (void)hipGraphExecDestroy(n->ro_graph);
+    if (n->comm) {
+        ncclCommDestroy((ncclComm_t)n->comm);
+        (void)hipGetLastError();   // RCCL teardown may leave a stale HIP error on this thread
+    }
     for (void *p : n->allocs) hipFree(p);
     delete n;
     return GRL_OK;
@@ -510,6 +554,64 @@ int grl_fnet_train_rollout(grl_fnet *net, float lr, float *stats_host) {
     if (net->h->cfg.env_kind == GRL_ENV_SOLOW)
         return train_device(net, n, net->ro_states, net->ro_hist, net->ro_act, net->ro_adv, net->ro_y, lr, 1, stats_host);
     return train_device(net, n, net->ro_states, nullptr, net->ro_act, net->ro_adv, net->ro_y, lr, 1, stats_host, net->ro_nhist);
+}
+
+// the gradient step in two halves for callers that exchange gradients themselves (host all-reduce through gloo when no RCCL
+// communicator can be formed): _grads leaves the LOCAL mean gradient in the net, nothing is updated
+int grl_fnet_train_rollout_grads(grl_fnet *net, float *stats_host) {
+    if (!net || !net->ro_states || net->T <= 0) return ffail(net, GRL_E_STATE, "grl_fnet_train_rollout_grads: no rollout to train on");
+    hipSetDevice(net->h->cfg.device_id);
+    const int n = net->T * net->h->E;
+    int rc = net->h->cfg.env_kind == GRL_ENV_SOLOW
+                 ? train_grads_device(net, n, net->ro_states, net->ro_hist, net->ro_act, net->ro_adv, net->ro_y)
+                 : train_grads_device(net, n, net->ro_states, nullptr, net->ro_act, net->ro_adv, net->ro_y, net->ro_nhist);
+    if (rc) return rc;
+    return train_apply_device(net, 0.f, 0, 1.0f, stats_host);
+}
+
+int grl_fnet_set_grads(grl_fnet *n, const float *host, int64_t cnt) { return fcopy_flat(n, n ? n->grads : nullptr, (float *)host, cnt, true); }
+
+int grl_fnet_apply_grads(grl_fnet *net, float lr, float grad_scale, float *stats_host) {
+    if (!net || net->last_n <= 0) return ffail(net, GRL_E_STATE, "grl_fnet_apply_grads: no gradient pass has run yet");
+    hipSetDevice(net->h->cfg.device_id);
+    return train_apply_device(net, lr, 1, grad_scale, stats_host);
+}
+
+int grl_fnet_comm_init(grl_fnet *net, const void *unique_id, size_t bytes, int32_t rank, int32_t world_size) {
+    if (!net || !unique_id || bytes != sizeof(ncclUniqueId) || world_size < 1 || rank < 0 || rank >= world_size)
+        return ffail(net, GRL_E_INVALID, "grl_fnet_comm_init: bad argument");
+    if (net->comm) return ffail(net, GRL_E_STATE, "grl_fnet_comm_init: communicator already attached");
+    hipSetDevice(net->h->cfg.device_id);
+    ncclUniqueId id;
+    memcpy(&id, unique_id, sizeof(id));
+    ncclComm_t comm;
+    ncclResult_t r = ncclCommInitRank(&comm, world_size, id, rank);
+    (void)hipGetLastError();
+    if (r != ncclSuccess) return ffail(net, GRL_E_COMM, std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
+    net->comm = (void *)comm; net->comm_world = world_size; net->comm_rank = rank;
+    return GRL_OK;
+}
+
+int grl_fnet_comm_broadcast_params(grl_fnet *net, int32_t root) {
+    if (!net || !net->comm) return ffail(net, GRL_E_STATE, "grl_fnet_comm_broadcast_params: no communicator");
+    hipSetDevice(net->h->cfg.device_id);
+    ncclResult_t r = ncclBroadcast(net->params, net->params, (size_t)net->off.total, ncclFloat, root, (ncclComm_t)net->comm, net->h->stream);
+    (void)hipGetLastError();
+    if (r != ncclSuccess) return ffail(net, GRL_E_COMM, std::string("ncclBroadcast: ") + ncclGetErrorString(r));
+    FNET_HIP(net, hipStreamSynchronize(net->h->stream));
+    return GRL_OK;
+}
+
+int grl_fnet_comm_destroy(grl_fnet *net) {
+    if (!net) return GRL_E_INVALID;
+    if (net->comm) {
+        hipSetDevice(net->h->cfg.device_id);
+        hipStreamSynchronize(net->h->stream);
+        ncclCommDestroy((ncclComm_t)net->comm);
+        (void)hipGetLastError();
+        net->comm = nullptr; net->comm_world = 1; net->comm_rank = 0;
+    }
+    return GRL_OK;
 }
 
 int grl_fnet_read_rollout(grl_fnet *net, const char *which, void *host, size_t bytes) {

@@ -31,6 +31,14 @@ FNET_SIGNATURES = {
     "grl_fnet_rollout": (C.c_int, [_P, _I]),
     "grl_fnet_train_rollout": (C.c_int, [_P, _F, _P]),
     "grl_fnet_read_rollout": (C.c_int, [_P, C.c_char_p, _P, _SZ]),
+    "grl_fnet_train_rollout_grads": (C.c_int, [_P, _P]),
+    "grl_fnet_set_grads": (C.c_int, [_P, _P, C.c_int64]),
+    "grl_fnet_apply_grads": (C.c_int, [_P, _F, _F, _P]),
+    "grl_fnet_comm_init": (C.c_int, [_P, _P, _SZ, _I, _I]),
+    "grl_fnet_comm_broadcast_params": (C.c_int, [_P, _I]),
+    "grl_fnet_comm_destroy": (C.c_int, [_P]),
+    "grl_comm_unique_id_bytes": (C.c_size_t, []),
+    "grl_comm_unique_id": (C.c_int, [_P, _SZ]),
 }
 
 
@@ -161,6 +169,41 @@ class FlatNet(object):
         stats = np.zeros(4, np.float32)
         self._check(self.lib.grl_fnet_train_rollout(self.n, lr, _ffi._ptr(stats)))
         return dict(zip(("loss", "policy_loss", "critic_loss_mean", "global_norm"), stats.tolist()))
+
+    def train_rollout_grads(self):
+        """Loss + backward over the last rollout only: the local mean gradient stays in the net (get_grads)."""
+        stats = np.zeros(4, np.float32)
+        self._check(self.lib.grl_fnet_train_rollout_grads(self.n, _ffi._ptr(stats)))
+        return dict(zip(("loss", "policy_loss", "critic_loss_mean", "global_norm"), stats.tolist()))
+
+    def set_grads(self, flat):
+        a = np.ascontiguousarray(flat, np.float32)
+        self._check(self.lib.grl_fnet_set_grads(self.n, _ffi._ptr(a), a.size))
+
+    def apply_grads(self, lr, grad_scale=1.0):
+        """clip_by_global_norm(grad_scale * grads) + Adam(lr) on the gradient currently in the net."""
+        stats = np.zeros(4, np.float32)
+        self._check(self.lib.grl_fnet_apply_grads(self.n, lr, grad_scale, _ffi._ptr(stats)))
+        return dict(zip(("loss", "policy_loss", "critic_loss_mean", "global_norm"), stats.tolist()))
+
+    # ---- multi-GPU: one RCCL all-reduce of the flat gradient per rollout (include/goldsrl_flatnet.h)
+    def comm_unique_id(self):
+        n = int(self.lib.grl_comm_unique_id_bytes())
+        buf = np.zeros(n, np.uint8)
+        rc = self.lib.grl_comm_unique_id(_ffi._ptr(buf), n)
+        if rc != _ffi.OK:
+            raise _ffi.GrlError(rc, "grl_comm_unique_id")
+        return buf
+
+    def comm_init(self, unique_id, rank, world_size):
+        buf = np.ascontiguousarray(unique_id, np.uint8)
+        self._check(self.lib.grl_fnet_comm_init(self.n, _ffi._ptr(buf), buf.size, rank, world_size))
+
+    def comm_broadcast_params(self, root=0):
+        self._check(self.lib.grl_fnet_comm_broadcast_params(self.n, root))
+
+    def comm_destroy(self):
+        self._check(self.lib.grl_fnet_comm_destroy(self.n))
 
     def read_rollout(self, which, shape):
         a = np.empty(shape, np.float32)

@@ -1,25 +1,57 @@
-"""Device-resident PAAC rollout + update for Swarm with the conv policy: the body of
-GridPAACLearner.train()'s while-loop (reference fed_gym/agents/paac/paac.py:302-387) as two C calls."""
+"""Device-resident PAAC rollout + update: the body of GridPAACLearner.train()'s while-loop (reference
+fed_gym/agents/paac/paac.py:302-387; Swarm, conv policy) and of PAACLearner.train()'s (paac.py:119-196; Solow / TradeAR1,
+FlatPolicyVNetwork) as two C calls each, plus the gradient exchange when the env batch is sharded over ranks."""
 from . import _ffi_net
 
 
-class ConvPolicyRollout(object):
+class _GradientExchange(object):
+    """What both rollouts do with the gradient: RCCL all-reduce inside train_rollout when a communicator is attached to the net,
+    otherwise (host_allreduce set) local gradient -> host sum over ranks -> clip + Adam on the mean of the ranks' means."""
+    host_allreduce = None      # callable(flat float32 gradient) -> (summed gradient, world size)
+
+    def _update(self):
+        if self.host_allreduce is None:
+            return self.net.train_rollout(self.lr)
+        self.net.train_rollout_grads()
+        summed, world = self.host_allreduce(self.net.get_grads())
+        self.net.set_grads(summed)
+        return self.net.apply_grads(self.lr, 1.0 / world)
+
+
+class ConvPolicyRollout(_GradientExchange):
     def __init__(self, eng, T, train=True, lr=1e-4, reward_layout=0, seed=3, chunk=40960, **net_kw):
         self.eng, self.T, self.train, self.lr, self.reward_layout = eng, T, train, lr, reward_layout
         chunk = min(chunk, eng.E * 10)
         self.net = _ffi_net.ConvNet(eng, max_chunk_samples=chunk, **net_kw)
         self.net.set_params(_ffi_net.glorot_uniform_flat(seed))
         self.last_stats = None
-        self.host_allreduce = None      # callable(flat float32 gradient) -> summed gradient, world size: gradient exchange on the host
 
     def run(self):
         self.net.rollout(self.T, self.reward_layout)
-        if not self.train:
-            return
-        if self.host_allreduce is None:
-            self.last_stats = self.net.train_rollout(self.lr)        # RCCL all-reduce inside when a communicator is attached
-        else:       # no device communicator: local gradient -> host exchange -> clip + Adam on the mean of the ranks' means
-            self.net.train_rollout_grads()
-            summed, world = self.host_allreduce(self.net.get_grads())
-            self.net.set_grads(summed)
-            self.last_stats = self.net.apply_grads(self.lr, 1.0 / world)
+        if self.train:
+            self.last_stats = self._update()
+
+
+class FlatPolicyRollout(_GradientExchange):
+    """Solow (BASELINE config 2) or TradeAR1 (config 5) handle + FlatPolicyVNetwork with the sizes the env dictates."""
+
+    def __init__(self, eng, T, train=True, lr=1e-4, seed=3, **net_kw):
+        from . import _ffi, _ffi_flat
+        self.eng, self.T, self.train, self.lr = eng, T, train, lr
+        if eng.kind == _ffi.ENV_TRADE:
+            S = 1 + 2 * eng.cfg.n_assets      # INPUT_SIZE = TEMPORAL_SIZE = 1+2n, NUM_ACTIONS = n (scripts/train_trade.py:38-40)
+            sizes = dict(static_size=S, temporal_size=S, num_actions=eng.cfg.n_assets)
+        else:
+            sizes = dict(static_size=2, temporal_size=2, num_actions=1)
+        net_kw.setdefault("rnn_length", eng.cfg.rnn_length)
+        net_kw.setdefault("max_samples", T * eng.E)
+        sizes.update(net_kw)
+        self.net = _ffi_flat.FlatNet(eng, **sizes)
+        self.net.set_params(_ffi_flat.default_init_flat(seed, static_size=sizes["static_size"], temporal_size=sizes["temporal_size"],
+                                                        num_actions=sizes["num_actions"]))
+        self.last_stats = None
+
+    def run(self):
+        self.net.rollout(self.T)
+        if self.train:
+            self.last_stats = self._update()

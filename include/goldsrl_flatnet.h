@@ -69,10 +69,26 @@ int grl_fnet_train(grl_fnet *net, int32_t n, const float *states, const float *h
  * returns.  TradeAR1 (BASELINE config 5; the reference has no PAAC runner for it) uses the net with
  * static_size = temporal_size = 1+2n, num_actions = n and the worker-style history window (quirk Q11). Async. */
 int grl_fnet_rollout(grl_fnet *net, int32_t T);
+/* Gradient step on the last rollout: [all-reduce over ranks if a communicator is attached], clip, Adam. */
 int grl_fnet_train_rollout(grl_fnet *net, float lr, float *stats_host);
+/* The same in two halves (as grl_net_train_rollout_grads / set_grads / apply_grads in goldsrl_net.h), for callers that sum the
+ * gradient over ranks themselves: _grads leaves the LOCAL mean gradient in the net (grl_fnet_get_grads) and updates nothing;
+ * grl_fnet_apply_grads: clip_by_global_norm(grad_scale * grads) + Adam(lr); grad_scale = 1/world after a sum over ranks. */
+int grl_fnet_train_rollout_grads(grl_fnet *net, float *stats_host);
+int grl_fnet_set_grads(grl_fnet *net, const float *host, int64_t n);
+int grl_fnet_apply_grads(grl_fnet *net, float lr, float grad_scale, float *stats_host);
 /* "actions" (T,E,A) "values" (T,E) "rewards" (T,E) raw "masks" (T,E) "y" (T,E) "adv" (T,E) "boot" (E,)
  * "states" (T,E,S0); Solow: "histories" (T,E,rnn,2); TradeAR1: "nhist" (T,E) int32 rows of the window */
 int grl_fnet_read_rollout(grl_fnet *net, const char *which, void *host, size_t bytes);
+
+/* ---- multi-GPU (BASELINE config 5: 65 536 TradeAR1 envs over 8 GPUs): one process per GPU owning a contiguous env block, one
+ * RCCL all-reduce (sum, fp32, ~31k floats: latency-bound) of the flat gradient per rollout; no counterpart in the reference
+ * (single device, actor_learner.py:70-75).  The loss is a batch mean (policy_v_network.py:246-251): the summed gradient is scaled
+ * by 1/world, clip_by_global_norm is applied after the reduction, Adam runs replicated.  Unique id: grl_comm_unique_id()
+ * (goldsrl_net.h), shipped to the ranks by the caller. */
+int grl_fnet_comm_init(grl_fnet *net, const void *unique_id, size_t bytes, int32_t rank, int32_t world_size);
+int grl_fnet_comm_broadcast_params(grl_fnet *net, int32_t root);
+int grl_fnet_comm_destroy(grl_fnet *net);
 
 #ifdef __cplusplus
 }
