@@ -107,6 +107,49 @@ static int action_cols(const grl_handle *h) {
     }
 }
 
+// R6 (paac.py:142-157, 331-349): one lane per env; finished episodes are compacted with a wave ballot + one atomicAdd per wave
+__global__ void episodes_account_kernel(const float *__restrict__ reward, const uint8_t *__restrict__ done, int E,
+                                        double *__restrict__ total, int32_t *__restrict__ len, int64_t *__restrict__ steps,
+                                        grl_episode_record *__restrict__ rec, int32_t *__restrict__ count, int cap) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = e < E;
+    double t = 0.0;
+    int32_t l = 0;
+    int64_t s = 0;
+    bool fin = false;
+    if (active) {
+        t = total[e] + (double)reward[e];
+        l = len[e] + 1;
+        s = steps[e] + 1;
+        fin = done[e] != 0;
+    }
+    const unsigned long long m = __ballot(fin);
+    if (m) {
+        const int lane = threadIdx.x & 63;
+        int base = 0;
+        if (lane == __ffsll((long long)m) - 1) base = atomicAdd(count, __popcll(m));
+        base = __shfl(base, __ffsll((long long)m) - 1);
+        if (fin) {
+            const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+            if (slot < cap) {
+                grl_episode_record r;
+                r.step_index = s; r.env = e; r.length = l; r.total_reward = t;
+                rec[slot] = r;
+            }
+            t = 0.0; l = 0;
+        }
+    }
+    if (active) { total[e] = t; len[e] = l; steps[e] = s; }
+}
+
+int episodes_launch_account(grl_handle *h) {
+    if (!h->ep_total) return GRL_OK;
+    hipLaunchKernelGGL(episodes_account_kernel, dim3((h->E + 255) / 256), dim3(256), 0, h->stream, h->reward, h->done, h->E, h->ep_total,
+                       h->ep_len, h->ep_steps, h->ep_rec, h->ep_count, h->ep_capacity);
+    GRL_HIP(h, hipGetLastError());
+    return GRL_OK;
+}
+
 static int reset_list(grl_handle *h, const int32_t *list_dev, const int32_t *count_dev, int max_count) {
     switch (h->cfg.env_kind) {
         case GRL_ENV_SWARM: return swarm_launch_reset(h, list_dev, count_dev, max_count);
@@ -179,6 +222,7 @@ int grl_create(const grl_config *cfg, grl_handle **out) {
     h->E = cfg->num_envs;
     h->step_in_flight = false;
     h->prof_on = false; h->prof_used = 0;
+    h->ep_total = nullptr; h->ep_len = nullptr; h->ep_steps = nullptr; h->ep_rec = nullptr; h->ep_count = nullptr; h->ep_capacity = 0;
     h->stream = nullptr; h->ev0 = nullptr; h->ev1 = nullptr;
     h->sw = {}; h->so = {}; h->tr = {}; h->tk = {};
     int rc = GRL_OK;
@@ -311,6 +355,7 @@ int grl_step_device(grl_handle *h, const float *actions_dev) {
         case GRL_ENV_TICKER: rc = ticker_launch_step(h, actions_dev); break;
         default: rc = trade_launch_step(h, actions_dev); break;
     }
+    if (rc == GRL_OK) rc = episodes_launch_account(h);
     if (rc == GRL_OK) h->step_in_flight = true;
     return rc;
 }
@@ -553,6 +598,56 @@ int grl_profile_read(grl_handle *h, int32_t *launches_out, float *total_ms_out) 
     }
     *launches_out = (int32_t)(h->prof_used / 2);
     *total_ms_out = total;
+    return GRL_OK;
+}
+
+int grl_episodes_enable(grl_handle *h, int32_t capacity) {
+    if (!h || capacity <= 0) return fail(h, GRL_E_INVALID, "grl_episodes_enable: capacity must be positive");
+    if (h->ep_total) return fail(h, GRL_E_STATE, "grl_episodes_enable: already enabled");
+    hipSetDevice(h->cfg.device_id);
+    const size_t E = h->E;
+    void *p[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    const size_t bytes[5] = {E * 8, E * 4, E * 8, (size_t)capacity * sizeof(grl_episode_record), 4};
+    for (int i = 0; i < 5; ++i) {
+        GRL_HIP(h, hipMalloc(&p[i], bytes[i]));
+        h->allocs.push_back(p[i]);
+        GRL_HIP(h, hipMemsetAsync(p[i], 0, bytes[i], h->stream));
+    }
+    GRL_HIP(h, hipStreamSynchronize(h->stream));
+    h->ep_len = (int32_t *)p[1]; h->ep_steps = (int64_t *)p[2]; h->ep_rec = (grl_episode_record *)p[3]; h->ep_count = (int32_t *)p[4];
+    h->ep_capacity = capacity;
+    h->ep_total = (double *)p[0];      // set last: this is the "enabled" flag
+    return GRL_OK;
+}
+
+int grl_episodes_read(grl_handle *h, grl_episode_record *out, int32_t max_records, int32_t *n_out, int32_t *dropped_out) {
+    if (!h || !n_out || max_records < 0 || (max_records > 0 && !out)) return fail(h, GRL_E_INVALID, "grl_episodes_read: bad argument");
+    if (!h->ep_total) return fail(h, GRL_E_STATE, "grl_episodes_read: call grl_episodes_enable first");
+    hipSetDevice(h->cfg.device_id);
+    GRL_HIP(h, hipStreamSynchronize(h->stream));
+    int32_t cnt = 0;
+    GRL_HIP(h, hipMemcpy(&cnt, h->ep_count, 4, hipMemcpyDeviceToHost));
+    const int32_t stored = cnt < h->ep_capacity ? cnt : h->ep_capacity;
+    if (stored > max_records) return fail(h, GRL_E_SIZE, "grl_episodes_read: " + std::to_string(stored) + " finished episodes, room for " + std::to_string(max_records));
+    if (stored > 0) {
+        GRL_HIP(h, hipMemcpy(out, h->ep_rec, (size_t)stored * sizeof(grl_episode_record), hipMemcpyDeviceToHost));
+        std::sort(out, out + stored, [](const grl_episode_record &a, const grl_episode_record &b) {
+            return a.step_index != b.step_index ? a.step_index < b.step_index : a.env < b.env;
+        });
+    }
+    GRL_HIP(h, hipMemset(h->ep_count, 0, 4));
+    *n_out = stored;
+    if (dropped_out) *dropped_out = cnt - stored;
+    return GRL_OK;
+}
+
+int grl_episodes_running(grl_handle *h, double *total_reward_out, int32_t *length_out) {
+    if (!h) return GRL_E_INVALID;
+    if (!h->ep_total) return fail(h, GRL_E_STATE, "grl_episodes_running: call grl_episodes_enable first");
+    hipSetDevice(h->cfg.device_id);
+    GRL_HIP(h, hipStreamSynchronize(h->stream));
+    if (total_reward_out) GRL_HIP(h, hipMemcpy(total_reward_out, h->ep_total, (size_t)h->E * 8, hipMemcpyDeviceToHost));
+    if (length_out) GRL_HIP(h, hipMemcpy(length_out, h->ep_len, (size_t)h->E * 4, hipMemcpyDeviceToHost));
     return GRL_OK;
 }
 

@@ -80,6 +80,13 @@ struct grl_handle {
     grl::TickerState tk;
     std::vector<void *> allocs;   // everything hipMalloc'ed by the handle
     std::vector<void *> user_allocs;
+    // R6 episode bookkeeping (grl_episodes_*): nullptr until enabled
+    double *ep_total;
+    int32_t *ep_len;
+    int64_t *ep_steps;
+    grl_episode_record *ep_rec;
+    int32_t *ep_count;
+    int32_t ep_capacity;
     // per-kernel profiling (grl_profile_*)
     bool prof_on;
     std::vector<hipEvent_t> prof_ev;   // pairs
@@ -98,6 +105,8 @@ int hip_fail(grl_handle *h, hipError_t e, const char *what);
         if (_e != hipSuccess) return grl::hip_fail(h, _e, #call); \
     } while (0)
 
+// api.hip: accounts the step just enqueued on the handle's stream (no-op until grl_episodes_enable)
+int episodes_launch_account(grl_handle *h);
 // swarm.hip
 int swarm_alloc(grl_handle *h);
 int swarm_launch_step(grl_handle *h, const float *actions_dev);

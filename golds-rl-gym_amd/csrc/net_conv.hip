@@ -105,7 +105,7 @@ struct grl_net : NetLane {
     float *stats;              // device: loss sums
     // rollout storage (allocated by grl_net_rollout)
     int T, B;
-    uint8_t *ro_lb, *ro_ab, *ro_pos;
+    uint8_t *ro_lb, *ro_ab, *ro_pos, *ro_done;      // ro_done (T,E): episode_over after each step (R6 / tests; the grid return ignores it, Q5)
     float *ro_act, *ro_envact, *ro_val, *ro_rew, *ro_y, *ro_adv, *ro_boot, *ro_sigma;
     float *mu, *sigma, *vs;    // (B,2) (B,2) (B) of the last predict
     uint8_t *tmp_lb, *tmp_ab, *tmp_pos;

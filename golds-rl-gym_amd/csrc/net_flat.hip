@@ -174,6 +174,7 @@ struct grl_fnet {
     uint32_t *d_counter;           // act_counter at the start of the rollout in flight
     hipGraphExec_t ro_graph;       // the T-step rollout captured once and replayed (launch-bound at 4 096 envs)
     int ro_graph_T;
+    bool ro_graph_ep;              // the captured rollout contains the R6 accounting launches
     int last_n;                    // samples of the last gradient pass (grl_fnet_apply_grads normalises the loss sums with it)
     void *comm;                    // ncclComm_t (RCCL): one all-reduce of the flat gradient per rollout, or nullptr
     int comm_world, comm_rank;
@@ -309,6 +310,7 @@ static int enqueue_rollout(grl_fnet *net, int T) {
                            net->ro_act + (size_t)t * E * A, net->ro_envact);
         rc = solow ? solow_launch_step(h, net->ro_envact) : trade_launch_step(h, net->ro_envact);
         if (rc) return ffail(net, rc, h->err);
+        if ((rc = episodes_launch_account(h))) return ffail(net, rc, h->err);      // R6 (paac.py:142-157), when enabled on the handle
         FNET_HIP(net, hipMemcpyAsync(net->ro_rew + (size_t)t * E, h->reward, (size_t)E * 4, hipMemcpyDeviceToDevice, st));
         hipLaunchKernelGGL(flat_mask_kernel, dim3((E + 255) / 256), dim3(256), 0, st, h->done, E, net->ro_mask + (size_t)t * E);
     }
@@ -365,7 +367,7 @@ int grl_fnet_create(grl_handle *h, const grl_fnet_config *cfg, grl_fnet **out) {
     Al(&n->mu, ms * A); Al(&n->sigma, ms * A); Al(&n->vs, ms);
     if (rc == GRL_OK) rc = falloc(n, &n->stats64, 8);
     if (rc == GRL_OK) rc = falloc(n, &n->d_counter, 4);
-    n->ro_graph = nullptr; n->ro_graph_T = 0;
+    n->ro_graph = nullptr; n->ro_graph_T = 0; n->ro_graph_ep = false;
     n->last_n = 0; n->comm = nullptr; n->comm_world = 1; n->comm_rank = 0;
     hipError_t e = hipSuccess;
     if (rc == GRL_OK) e = hipFuncSetAttribute((const void *)flat_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLAT_LDS_BYTES);
@@ -517,7 +519,7 @@ int grl_fnet_rollout(grl_fnet *net, int32_t T) {
     // draw counter of step t = act_counter + t, read by the sample kernel from device memory
     FNET_HIP(net, hipMemsetD32Async((hipDeviceptr_t)net->d_counter, (int)(uint32_t)net->act_counter, 1, st));
     net->act_counter += (unsigned long)T;
-    if (net->ro_graph && net->ro_graph_T == T) {
+    if (net->ro_graph && net->ro_graph_T == T && net->ro_graph_ep == (h->ep_total != nullptr)) {
         FNET_HIP(net, hipGraphLaunch(net->ro_graph, st));
     } else {
         if (net->ro_graph) { (void)hipGraphExecDestroy(net->ro_graph); net->ro_graph = nullptr; }
@@ -530,6 +532,7 @@ int grl_fnet_rollout(grl_fnet *net, int32_t T) {
             hipError_t e = hipStreamEndCapture(st, &graph);
             if (rc == GRL_OK && e == hipSuccess && graph && hipGraphInstantiate(&net->ro_graph, graph, nullptr, nullptr, 0) == hipSuccess) {
                 net->ro_graph_T = T;
+                net->ro_graph_ep = h->ep_total != nullptr;
             } else {
                 net->ro_graph = nullptr;
                 (void)hipGetLastError();

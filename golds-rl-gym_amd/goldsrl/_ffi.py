@@ -82,7 +82,13 @@ SIGNATURES = {
     "grl_timer_start": (C.c_int, [_P]),
     "grl_timer_stop": (C.c_int, [_P]),
     "grl_timer_ms": (C.c_int, [_P, C.POINTER(C.c_float)]),
+    "grl_episodes_enable": (C.c_int, [_P, _I]),
+    "grl_episodes_read": (C.c_int, [_P, _P, _I, C.POINTER(_I), C.POINTER(_I)]),
+    "grl_episodes_running": (C.c_int, [_P, _P, _P]),
 }
+
+# grl_episode_record (include/goldsrl.h)
+EPISODE_DTYPE = np.dtype([("step_index", np.int64), ("env", np.int32), ("length", np.int32), ("total_reward", np.float64)])
 
 
 def load_library(path=None, extra_signatures=None):
@@ -328,6 +334,26 @@ class Engine(object):
         n, ms = C.c_int32(), C.c_float()
         self._check(self.lib.grl_profile_read(self.h, C.byref(n), C.byref(ms)))
         return n.value, ms.value
+
+    # -- R6: per-env episode bookkeeping of the learner loop (paac.py:142-157, 331-349), kept on the device
+    def episodes_enable(self, capacity=None):
+        self._ep_capacity = int(capacity if capacity is not None else max(1024, 32 * self.E))
+        self._check(self.lib.grl_episodes_enable(self.h, self._ep_capacity))
+
+    def episodes_read(self):
+        """Finished episodes since the last read, in the reference's append order (step, env): structured array
+        (step_index, env, length, total_reward).  Raises if records were dropped (capacity too small for the read interval)."""
+        buf = np.zeros(self._ep_capacity, EPISODE_DTYPE)
+        n, dropped = C.c_int32(), C.c_int32()
+        self._check(self.lib.grl_episodes_read(self.h, _ptr(buf), self._ep_capacity, C.byref(n), C.byref(dropped)))
+        if dropped.value:
+            raise GrlError(-1, "%d finished episodes were dropped: raise the capacity of episodes_enable()" % dropped.value)
+        return buf[:n.value].copy()
+
+    def episodes_running(self):
+        tot, ln = np.zeros(self.E, np.float64), np.zeros(self.E, np.int32)
+        self._check(self.lib.grl_episodes_running(self.h, _ptr(tot), _ptr(ln)))
+        return tot, ln
 
     def timer_start(self):
         self._check(self.lib.grl_timer_start(self.h))

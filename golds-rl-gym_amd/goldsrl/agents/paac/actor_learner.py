@@ -19,12 +19,20 @@ class ActorLearner(object):
         self.checkpoint_every = getattr(args, 'checkpoint_every', 0)    # updates between flat-weights checkpoints (0: never)
         self.checkpoint_path = getattr(args, 'checkpoint_path', 'checkpoint.npz')
         self.resume = getattr(args, 'resume', None)
+        if getattr(args, 'max_episode_steps', None):       # TimeLimit of the registered id (fed_gym/__init__.py); tests shorten it
+            self.max_episode_steps = int(args.max_episode_steps)
+        if getattr(args, 'seed', None) is not None:
+            self.seed = int(args.seed)
         self.summary_writer = None      # created by train() when args.summaries is set (actor_learner.py:79-83)
         self.summaries = bool(getattr(args, 'summaries', False))
         self.network_creator = network_creator
         self.environment_creator = environment_creator
         self.network = network_creator()
         self.runners = None
+        self.total_rewards = []     # reward per step of every finished training episode (paac.py:60,150,342)
+        self.episode_log = []       # (global_step, env, length, total_reward) per finished episode = the `rl/reward` points
+        self.ranks = None           # goldsrl.distributed.Ranks, formed by train()
+        self.gradient_exchange = "none"
 
     def rescale_reward(self, reward, lb=-2, ub=2):
         """Clip immediate reward (actor_learner.py:91-97)."""

@@ -231,6 +231,30 @@ int grl_timer_ms(grl_handle *h, float *ms_out);
 int grl_profile_enable(grl_handle *h, int32_t on);
 int grl_profile_read(grl_handle *h, int32_t *launches_out, float *total_ms_out);
 
+/* ---- R6: the learner's per-env bookkeeping (fed_gym/agents/paac/paac.py:142-157 flat, :331-349 grid) kept on the device next
+ * to the env state, because the actor loop runs there.  For every env step taken through the handle after grl_episodes_enable
+ * (grl_step_*, grl_net_rollout, grl_fnet_rollout), per env e:
+ *     total_episode_rewards[e] += reward[e]   (the float32 the learner reads, summed in float64 as numpy 1.13 does for
+ *                                              `0 + np.float32`; unclipped: the clip of :145 applies to the stored reward only)
+ *     emulator_steps[e] += 1
+ *     if episode_over[e]: append {step_index, e, emulator_steps[e], total_episode_rewards[e]}; both are zeroed.
+ * step_index counts the steps the env has taken since enable (1-based; all envs of a handle step in lockstep), so the
+ * reference's global_step at the moment of the record (global_step += 1 per env in e order, :149/:341) is
+ *     global_step_at_enable + (step_index - 1) * num_envs + env + 1
+ * and `rl/reward` = total_reward, total_rewards.append(total_reward / length) (:150-155, :342-347).
+ * grl_episodes_read waits for the stream, returns the finished episodes ordered by (step_index, env) -- the reference's append
+ * order -- and empties the list.  *dropped_out = records lost because more than `capacity` episodes finished between two reads. */
+typedef struct grl_episode_record {
+    int64_t step_index;
+    int32_t env;      /* local env index of the handle */
+    int32_t length;   /* emulator_steps[e] at the end of the episode */
+    double total_reward;
+} grl_episode_record;
+int grl_episodes_enable(grl_handle *h, int32_t capacity);
+int grl_episodes_read(grl_handle *h, grl_episode_record *out, int32_t max_records, int32_t *n_out, int32_t *dropped_out);
+/* the running accumulators (host arrays of num_envs entries; either may be NULL) */
+int grl_episodes_running(grl_handle *h, double *total_reward_out, int32_t *length_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -287,6 +287,29 @@ def nstep_returns(rewards, values, boot, gamma, masks=None):
     return y, adv
 
 
+def episode_bookkeeping(rewards, dones, total=None, steps=None, global_step=0):
+    """The learner's per-env bookkeeping inside the rollout loop (agents/paac/paac.py:142-157 flat, :331-349 grid; the grid
+    form reads column 0 of the broadcast reward/done rows, i.e. the env's scalar).  rewards (T,E) float32 as the shared
+    array holds them, dones (T,E).  Returns (records, total, steps, global_step): records in append order, each
+    (global_step at the add_summary call, env, episode length, total_episode_reward) -- `rl/reward` is the total,
+    total_rewards.append(total / length).  total_episode_rewards starts as int 0, so under the reference's numpy 1.13.3
+    `0 + np.float32` promotes to float64 and the sum stays float64 (numpy 2 would keep float32): float64 here."""
+    T, E = rewards.shape
+    total = np.zeros(E, np.float64) if total is None else np.array(total, np.float64)
+    steps = np.zeros(E, np.int64) if steps is None else np.array(steps, np.int64)
+    records = []
+    for t in range(T):
+        for e in range(E):
+            total[e] += np.float64(np.float32(rewards[t, e]))
+            steps[e] += 1
+            global_step += 1
+            if dones[t, e]:
+                records.append((global_step, e, int(steps[e]), float(total[e])))
+                total[e] = 0.0
+                steps[e] = 0
+    return records, total, steps, global_step
+
+
 def gae(rewards, values, boot, gamma, lam):
     """A3C GAE (agents/a3c/worker.py:232-239, 284-294): delta_t = r_t + g V_{t+1} - V_t,
     adv = lfilter([1],[1,-g*lam]) over reversed time, target = adv + V_t.  (T,B) inputs."""
