@@ -170,7 +170,15 @@ def cpu_baseline(sample_envs, T, full_update_envs=48):
     dt = time.perf_counter() - t0
     if limiter is not None:
         limiter.restore_original_limits() if hasattr(limiter, "restore_original_limits") else None
-    return {"value": Ef * T / dt, "unit": "env-steps/s", "cores": ncores, "kind": "port",
+    ref_note = None      # the reference's own Python path, timed in the build container (it cannot travel): BASELINE.md section 3.1
+    rpath = os.path.join(ROOT, "profiles", "r02_reference_cpu.json")
+    if os.path.exists(rpath):
+        with open(rpath) as f:
+            rj = json.load(f)
+        ref_note = {"where": rj["where"], "swarm_single_process_env_steps_per_s": rj["single_process"][0]["env_steps_per_s"],
+                    "swarm_gridrunners_8_workers_env_steps_per_s": {str(r["envs"]): r["env_steps_per_s"] for r in rj["runners"] if r["env"] == "Swarm-v0"},
+                    "note": "unmodified reference (env step + auto-reset + process_state + get_local_states, no policy), NOT measured in this run"}
+    return {"value": Ef * T / dt, "unit": "env-steps/s", "cores": ncores, "kind": "port", "reference_python_build_container": ref_note,
             "sample": "oracle full PAAC update (oracle/nets.py float64 numpy conv policy fwd+bwd+clip+Adam, oracle/oracle_c.c env "
                       "step+observation, dense 84x84x3 images as the reference feeds them) on %d envs x %d steps: %.1f s" % (Ef, T, dt),
             "env_only_value": env_only["allcores"], "env_only_value_1core": env_only["1core"],
