@@ -367,6 +367,22 @@ int grl_step_async(grl_handle *h, const float *actions_host) {
     return grl_step_device(h, h->actions);
 }
 
+int grl_swarm_step_f64(grl_handle *h, const double *actions_host) {
+    if (!h || !actions_host) return fail(h, GRL_E_INVALID, "grl_swarm_step_f64: null argument");
+    if (h->cfg.env_kind != GRL_ENV_SWARM) return fail(h, GRL_E_INVALID, "grl_swarm_step_f64: not a Swarm handle");
+    hipSetDevice(h->cfg.device_id);
+    const size_t bytes = (size_t)h->E * N_AGENTS * 2 * sizeof(double);
+    if (!h->sw.act64) {
+        GRL_HIP(h, hipMalloc((void **)&h->sw.act64, bytes));
+        h->allocs.push_back(h->sw.act64);
+    }
+    GRL_HIP(h, hipMemcpyAsync(h->sw.act64, actions_host, bytes, hipMemcpyHostToDevice, h->stream));
+    int rc = swarm_launch_step(h, nullptr, h->sw.act64);
+    if (rc == GRL_OK) rc = episodes_launch_account(h);
+    if (rc == GRL_OK) h->step_in_flight = true;
+    return rc;
+}
+
 int grl_wait(grl_handle *h) {
     if (!h) return GRL_E_INVALID;
     hipSetDevice(h->cfg.device_id);

@@ -26,6 +26,7 @@ struct SwarmState {
     double *x, *xa, *pnoise, *anoise;              // (E,80,2) (E,10,2) (E,80,2) (E,10,2)
     double *rx, *rxa, *rpnoise, *ranoise;          // reset snapshot (allocated on first use)
     double *reward64;
+    double *act64;                                 // staging of grl_swarm_step_f64 (allocated on first use)
     uint8_t *lbins, *abins, *pos;
 };
 
@@ -109,7 +110,7 @@ int hip_fail(grl_handle *h, hipError_t e, const char *what);
 int episodes_launch_account(grl_handle *h);
 // swarm.hip
 int swarm_alloc(grl_handle *h);
-int swarm_launch_step(grl_handle *h, const float *actions_dev);
+int swarm_launch_step(grl_handle *h, const float *actions_dev, const double *actions64_dev = nullptr);
 int swarm_launch_reset(grl_handle *h, const int32_t *list_dev, const int32_t *count_dev, int max_count);
 int swarm_launch_observe(grl_handle *h);
 int swarm_reset_injected(grl_handle *h, const double *x0, const double *xa0, const double *ra,

@@ -58,7 +58,9 @@ __device__ __forceinline__ float solow_reset_env(const SolowParams &S, int env) 
     for (int i = 0; i < S.Q; ++i) S.e[(size_t)i * S.E + env] = 0.f;
     const bool fixed = S.flags & (GRL_F_RESET_FROM_SNAPSHOT | GRL_F_RESEED_EACH_RESET);
     float zl = 0.f;
-    if (fixed && (S.flags & GRL_F_RESET_FROM_SNAPSHOT)) {
+    if (S.flags & GRL_F_SOLOW_SS_RESET) {      // SolowSSEnv._reset (fed_env.py:259): self.z = np.array([0.])
+        for (int i = 0; i < S.P; ++i) S.z[(size_t)i * S.E + env] = 0.f;
+    } else if (fixed && (S.flags & GRL_F_RESET_FROM_SNAPSHOT)) {
         for (int i = 0; i < S.P; ++i) { zl = S.z0[(size_t)i * S.E + env]; S.z[(size_t)i * S.E + env] = zl; }
     } else {
         uint32_t ep = (S.flags & GRL_F_RESEED_EACH_RESET) ? 0u : (uint32_t)S.episode[env];

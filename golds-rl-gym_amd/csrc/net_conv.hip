@@ -79,6 +79,7 @@ struct NetLane {
     float *slab1h;             // one-hot conv1 tap partials of agent_ds_kernel
     float *slabb;              // per-wave-tile column sums written by the EpiGradSum / EpiGradStride2 data-gradient GEMMs (bias gradients)
     float *slab1b;             // per-workgroup sums of agent_ds_kernel's dS corrections (conv1's bias gradient)
+    float *cfold;              // kFoldParts x 32 partial sums of fold_class_sums_kernel
     double *slab64;
     float *ro_mu;              // chunk-sized scratch of the gradient step (cmu csigma cvs dzh cact cadv cy)
     float *ws_a3, *ws_d1, *ws_d2, *ws_p1, *ws_v1, *ws_v2, *ws_a3sh, *ws_d3;   // chunk workspace (the default binding)

@@ -20,6 +20,7 @@ struct SwarmParams {
     const double *rx, *rxa, *rpn, *ran;               // reset snapshot
     const double *inj_x0, *inj_xa0, *inj_ra, *inj_an, *inj_pn;  // injected reset draws
     const float *actions;
+    const double *actions64;     // if set: float64 actions (SwarmEnv.step called directly, e.g. by the eval monitor) instead of `actions`
     int32_t *elapsed, *episode;
     float *reward;
     double *reward64;
@@ -212,8 +213,13 @@ __global__ __launch_bounds__(SWARM_TPB) void swarm_kernel(SwarmParams P) {
             pnx = n.x; pny = n.y;
         }
         if (aactive) {
-            float2 act = reinterpret_cast<const float2 *>(P.actions)[(size_t)aenv * N_AGENTS + a];
-            actx = (double)act.x; acty = (double)act.y;
+            if (P.actions64) {
+                double2 act = reinterpret_cast<const double2 *>(P.actions64)[(size_t)aenv * N_AGENTS + a];
+                actx = act.x; acty = act.y;
+            } else {
+                float2 act = reinterpret_cast<const float2 *>(P.actions)[(size_t)aenv * N_AGENTS + a];
+                actx = (double)act.x; acty = (double)act.y;
+            }
             double2 n = reinterpret_cast<const double2 *>(P.anoise)[(size_t)aenv * N_AGENTS + a];
             anx = n.x; any = n.y;
         }
@@ -442,9 +448,10 @@ int swarm_alloc(grl_handle *h) {
 
 static inline int nblocks(int n) { return (n + SWARM_EPB - 1) / SWARM_EPB; }
 
-int swarm_launch_step(grl_handle *h, const float *actions_dev) {
+int swarm_launch_step(grl_handle *h, const float *actions_dev, const double *actions64_dev) {
     SwarmParams P = make_params(h);
     P.actions = actions_dev;
+    P.actions64 = actions64_dev;
     GRL_HIP(h, hipMemsetAsync(h->done_count, 0, sizeof(int32_t), h->stream));
     prof_begin(h);
     if (h->cfg.flags & GRL_F_SWARM_FAST_MATH)

@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libgoldsrl.so")
 
 ENV_SWARM, ENV_SOLOW, ENV_TRADE, ENV_TICKER = 0, 1, 2, 3
-F_RESEED_EACH_RESET, F_RESET_FROM_SNAPSHOT, F_INJECT_NOISE, F_SWARM_FAST_MATH, F_SWARM_NO_OBSERVE = 1, 2, 4, 8, 16
+F_RESEED_EACH_RESET, F_RESET_FROM_SNAPSHOT, F_INJECT_NOISE, F_SWARM_FAST_MATH, F_SWARM_NO_OBSERVE, F_SOLOW_SS_RESET = 1, 2, 4, 8, 16, 32
 
 OK, E_INVALID, E_NO_DEVICE, E_HIP, E_SIZE, E_ACTION_RANGE, E_STATE, E_COMM = 0, -1, -2, -3, -4, -5, -6, -7
 
@@ -82,6 +82,7 @@ SIGNATURES = {
     "grl_timer_start": (C.c_int, [_P]),
     "grl_timer_stop": (C.c_int, [_P]),
     "grl_timer_ms": (C.c_int, [_P, C.POINTER(C.c_float)]),
+    "grl_swarm_step_f64": (C.c_int, [_P, _P]),
     "grl_episodes_enable": (C.c_int, [_P, _I]),
     "grl_episodes_read": (C.c_int, [_P, _P, _I, C.POINTER(_I), C.POINTER(_I)]),
     "grl_episodes_running": (C.c_int, [_P, _P, _P]),
@@ -188,6 +189,14 @@ class Engine(object):
         else:
             a = np.ascontiguousarray(idx, dtype=np.int32)
             self._check(self.lib.grl_reset(self.h, _ptr(a), a.size))
+
+    def swarm_step_f64(self, actions):
+        """SwarmEnv.step with float64 actions (the eval monitor's call); synchronous like step()."""
+        a = np.ascontiguousarray(actions, dtype=np.float64)
+        if a.shape != (self.E, 10, 2):
+            raise ValueError("swarm_step_f64: expected shape %s, got %s" % ((self.E, 10, 2), a.shape))
+        self._check(self.lib.grl_swarm_step_f64(self.h, _ptr(a)))
+        self.wait()
 
     def swarm_reset_injected(self, x0, xa0, random_actions, agent_noise, particle_noise):
         arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (x0, xa0, random_actions, agent_noise, particle_noise)]

@@ -163,7 +163,10 @@ class SwarmPolicyMonitor(PolicyMonitor):
         # the device net reads the eval engine's current observation (process_state + get_local_states run on the device)
         predictions = self.policy_net.predict()
         mu, sigma = predictions['mu'], predictions['sigma']
-        raw_actions = mu + sigma * np.random.normal(size=mu.shape)
+        # policy_monitor.py:132 draws np.random.normal from the GLOBAL stream, which Swarm-eval-v0's reset has just reseeded
+        # (multiagent.py:47-48): the seeded facade exposes that stream as env.np_random
+        rng = getattr(self.env, "np_random", None) or np.random
+        raw_actions = mu + sigma * rng.normal(size=mu.shape)
         return SwarmRunner.transform_actions_for_env(raw_actions)
 
     @staticmethod

@@ -17,12 +17,12 @@ class SolowEnv(object):
     """Classic Solow model with ARMA(p,q) TFP shock and log-consumption reward (fed_env.py:161-250).
     State is float32 on the device (BASELINE north_star), observations come back as float64 arrays."""
 
-    def __init__(self, delta=0.02, sigma=0.1, p=1, q=1, T=None, seed=None, max_episode_steps=None, device_id=0):
+    def __init__(self, delta=0.02, sigma=0.1, p=1, q=1, T=None, seed=None, max_episode_steps=None, device_id=0, _extra_flags=0):
         self.delta, self.sigma, self.alpha = delta, sigma, 0.33
         self.seed_value = seed
         self.T = T if T else 2048
         self.p, self.q = p, q
-        flags = _ffi.F_RESEED_EACH_RESET if seed else 0
+        flags = (_ffi.F_RESEED_EACH_RESET if seed else 0) | _extra_flags
         self._eng = _ffi.Engine(_ffi.ENV_SOLOW, 1, device_id=device_id, seed=int(seed if seed else 1692), flags=flags,
                                 solow_p=p, solow_q=q, solow_tape_len=self.T + (self.T & 1), solow_sigma=sigma, solow_delta=delta,
                                 max_episode_steps=int(max_episode_steps or 0))
@@ -41,6 +41,14 @@ class SolowEnv(object):
 
     def seed(self, seed=None):
         return []
+
+
+class SolowSSEnv(SolowEnv):
+    """fed_env.py:253-265: sigma = 0.02, p = 1, q = 0; reset puts z = 0 (not a draw), e = 0, k = k_ss(alpha)."""
+
+    def __init__(self, delta=0.02, sigma=0.02, T=None, max_episode_steps=None, device_id=0):
+        super(SolowSSEnv, self).__init__(delta, sigma, p=1, q=0, T=T, max_episode_steps=max_episode_steps, device_id=device_id,
+                                         _extra_flags=_ffi.F_SOLOW_SS_RESET)
 
 
 class TradeAR1Env(object):

@@ -69,6 +69,9 @@ extern "C" {
 #define GRL_F_SWARM_FAST_MATH 0x8u
 /* Swarm: do not run the observation (binning) stage inside the step kernel. */
 #define GRL_F_SWARM_NO_OBSERVE 0x10u
+/* Solow: SolowSSEnv's reset (fed_env.py:257-265; id SolowSS-v0, fed_gym/__init__.py:15-19): z = 0 instead of z ~ N(0, sigma),
+ * e = 0, k = k_ss(alpha); the shock tape is still drawn.  Use with solow_p = 1, solow_q = 0, solow_sigma = 0.02. */
+#define GRL_F_SOLOW_SS_RESET 0x20u
 
 typedef struct grl_config {
     int32_t struct_size;       /* = sizeof(grl_config); guards against ABI drift */
@@ -180,6 +183,11 @@ int grl_get_state(grl_handle *h, int32_t field, void *host, size_t bytes);
  * rollout path).  Both only enqueue work on the handle's stream. */
 int grl_step_async(grl_handle *h, const float *actions_host);
 int grl_step_device(grl_handle *h, const float *actions_dev);
+/* Swarm only: the step with FLOAT64 host actions (E,10,2), for callers that hand SwarmEnv.step a float64 array directly -- the
+ * eval monitor does (policy_monitor.py:173-178: mu + sigma * np.random.normal is float64), while the learner's actions pass
+ * through the float32 shared array (quirk Q7) and use grl_step_async.  The dynamics are chaotic (~1.15x per step), so a
+ * float32-rounded action shows up as 4e-4 in the reward after 128 steps. */
+int grl_swarm_step_f64(grl_handle *h, const double *actions_host);
 int grl_wait(grl_handle *h);                       /* hipStreamSynchronize + deferred error checks */
 int grl_outputs(grl_handle *h, grl_out_ptrs *out); /* device pointers */
 /* Copy one output to the host: which = name of a grl_out_ptrs member, e.g. "reward". */

@@ -223,7 +223,6 @@ def test_swarm_policy_monitor_eval_episode(tmp_path):
     writer = PM.ScalarWriter(str(tmp_path / "eval"))
     mon = PM.SwarmPolicyMonitor(env, global_net, SwarmStateProcessor(grid_size=84), writer, network_conf=_conv_conf())
     mon.actions_path = str(tmp_path / "swarm-eval.json")
-    np.random.seed(0)
     total, length, rewards = mon.eval_once()
     assert length == 128 and len(rewards) == 128 and np.isfinite(total) and total < 0      # TimeLimit cap; rewards are -energy
     assert np.array_equal(mon.policy_net.get_flat_params(), global_net.get_flat_params())  # copy_params_op
@@ -238,6 +237,63 @@ def test_swarm_policy_monitor_eval_episode(tmp_path):
     np.testing.assert_allclose(rewards2, rewards, rtol=1e-12)
     lines = [json.loads(l) for l in open(tmp_path / "eval" / "scalars.jsonl")]
     assert {l["tag"] for l in lines} == {"eval/total_reward", "eval/episode_length"}
+
+
+def test_swarm_eval_env_plays_the_references_seed_192_episode(golden, tmp_path):
+    """SURVEY 8(f) rank 1, oracle-checked: `Swarm-eval-v0` (SwarmEnv(seed=192), fed_gym/__init__.py:28-33) resets to the
+    REFERENCE's state (its MT19937 draws + 10 burn-in steps: tests/golden/swarm_reset.npz) and, with the reference's scripted
+    actions replayed through SwarmPolicyMonitor.eval_once(actions=queue) (policy_monitor.py:156-176), reproduces the reference's
+    128-step episode of tests/golden/swarm_traj.npz step for step (rewards, done at the TimeLimit, positions every 16 steps)."""
+    import queue
+    from goldsrl import envs, _ffi
+    from goldsrl.agents.paac import policy_monitor as PM
+    from goldsrl.agents.paac.policy_v_network import ConvSingleAgentPolicyNetwork
+    from goldsrl.agents.state_processors import SwarmStateProcessor
+    g, r0 = golden("swarm_traj"), golden("swarm_reset")
+    env = envs.make("Swarm-eval-v0")
+    for _ in range(2):                     # every reset re-seeds: the same state each time
+        x, xa = env.reset()
+        np.testing.assert_allclose(xa, r0["s192_xa"], rtol=1e-13, atol=1e-14)
+        np.testing.assert_allclose(x, r0["s192_x"], rtol=1e-11, atol=1e-12)      # 10 chained burn-in steps
+    assert np.array_equal(env._eng.get_state("SWARM_ANOISE")[0], g["agent_noise_row"])      # row 10 of the reference's tables
+    assert np.array_equal(env._eng.get_state("SWARM_PNOISE")[0], g["particle_noise_row"])
+    # the stream continues where the reference's global generator would: its next draws are the monitor's action noise
+    rs = np.random.RandomState(192)
+    rs.rand(80, 2); rs.rand(10, 2); rs.normal(size=(10, 10, 2)); rs.normal(size=(138, 10, 2)); rs.normal(size=(138, 80, 2))
+    assert np.array_equal(env.np_random.normal(size=(10, 2)), rs.normal(size=(10, 2)))
+    # scripted episode through the monitor
+    learner_eng = _ffi.Engine(_ffi.ENV_SWARM, 2, seed=5)
+    learner_eng.reset()
+    global_net = ConvSingleAgentPolicyNetwork(_conv_conf()).bind(learner_eng, seed=11)
+    mon = PM.SwarmPolicyMonitor(env, global_net, SwarmStateProcessor(grid_size=84), PM.ScalarWriter(str(tmp_path / "eval")),
+                                network_conf=_conv_conf())
+    mon.actions_path = str(tmp_path / "swarm-eval.json")
+    snaps = {}
+    inner_step = env.step
+
+    def recording_step(a):
+        out = inner_step(a)
+        snaps[len(snaps)] = (out[0][0].copy(), out[0][1].copy())
+        return out
+    env.step = recording_step
+    q = queue.Queue()
+    for a in g["actions"][:128]:
+        q.put(a)
+    total, length, rewards = mon.eval_once(actions=q)
+    assert length == 128 and q.empty()                       # done exactly at the TimeLimit (dones[127] in the fixture)
+    assert bool(g["dones"][127]) and not g["dones"][:127].any()
+    np.testing.assert_allclose(rewards, g["rewards"][:128], rtol=1e-9)
+    np.testing.assert_allclose(total, np.sum(g["rewards"][:128]), rtol=1e-10)
+    for i, step in enumerate(g["snap_steps"]):
+        if step >= 127:
+            break                                             # at 127 the fixture holds the reset state (worker rule)
+        np.testing.assert_allclose(snaps[int(step)][1], g["xa_snap"][i], rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(snaps[int(step)][0], g["x_snap"][i], rtol=1e-7, atol=1e-9)      # 16..112 chained chaotic steps
+    # and the policy-driven episode is deterministic: action noise comes from the re-seeded stream (policy_monitor.py:132)
+    env.step = inner_step
+    t1, l1, rew1 = mon.eval_once()
+    t2, l2, rew2 = mon.eval_once()
+    assert l1 == l2 == 128 and rew1 == rew2
 
 
 def test_solow_policy_monitor_and_checkpoint(tmp_path):

@@ -274,6 +274,32 @@ def test_solow_steps_golden(golden, p, q):
     np.testing.assert_allclose(eng.read("obs")[0], O.solow_process_state(g[k_ + "obs"][-1]), rtol=1e-5, atol=1e-6)
 
 
+def test_solow_ss_env_golden(golden):
+    # `SolowSS-v0` / SolowSSEnv (fed_gym/__init__.py:15-19, fed_env.py:253-265) through the gym-style facade: reset gives
+    # [k_ss(alpha), 0.] (z is NOT drawn), then the reference's own trajectory with its shock tape injected
+    from goldsrl import envs
+    g = golden("solow_ss")
+    assert envs.registry["SolowSS-v0"][1] == int(g["max_episode_steps"]) == 1024
+    env = envs.make("SolowSS-v0")
+    assert isinstance(env, envs.SolowSSEnv) and (env.sigma, env.p, env.q) == (float(g["sigma"]), 1, 0)
+    for _ in range(2):      # every reset puts z back to 0
+        obs0 = env.reset()
+        np.testing.assert_allclose(obs0, g["obs0"], rtol=1e-6)
+        assert obs0[1] == 0.0
+        tape = np.zeros(env._eng.cfg.solow_tape_len, np.float32)
+        tape[-64:] = g["tape_tail"]
+        env._eng.set_state("SOLOW_TAPE", tape[None])
+        for t, s in enumerate(g["s"]):
+            obs, rew, done, info = env.step(s)
+            np.testing.assert_allclose(obs, g["obs"][t], rtol=1e-5, atol=1e-6)
+            np.testing.assert_allclose(rew, g["reward"][t], rtol=1e-5, atol=2e-6)
+            assert done is False and info == {}
+    # the device generator draws a sigma = 0.02 tape for it (statistics of 2048 draws)
+    env.reset()
+    drawn = env._eng.get_state("SOLOW_TAPE")[0]
+    assert abs(drawn.std() - 0.02) < 0.002 and abs(drawn.mean()) < 0.002
+
+
 def test_solow_steady_state_closed_form(golden):
     # tests/env_tests.py:145-155: sigma = 0, s = 0.1 -> k converges to (s/delta)^(1/(1-alpha))
     g = golden("solow")

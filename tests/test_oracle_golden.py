@@ -98,6 +98,22 @@ def test_solow(golden):
     assert np.array_equal(O.solow_process_state(g["proc_in"]), g["proc_out"])
 
 
+def test_solow_ss(golden):
+    # SolowSSEnv (fed_env.py:253-265): p=1, q=0, sigma=0.02; reset z = 0, e = 0, k = k_ss(alpha)
+    g = golden("solow_ss")
+    rho_z, rho_e = O.solow_rhos(1, 0)
+    assert np.array_equal(rho_z, g["rho_z"]) and float(g["rho_e"]) == 0.5 and int(g["max_episode_steps"]) == 1024
+    k, z, e = np.array([O.solow_k_ss(0.33)]), np.zeros((1, 1)), np.zeros((1, 1))
+    assert np.array_equal(g["obs0"], [k[0], 0.0])
+    tape = list(g["tape_tail"])
+    for t, s in enumerate(g["s"]):
+        k, z, e_, obs, rew = O.solow_step(k, z, e, np.array([tape.pop()]), np.array([s]), rho_z, rho_e)
+        # q = 0: the MA window is the scalar e_t of the previous step (fed_env.py:224-227 keeps self.e = [e_t])
+        e = e_[:, -1:]
+        np.testing.assert_allclose(obs[0], g["obs"][t], rtol=1e-15, atol=0)
+        np.testing.assert_allclose(rew[0], g["reward"][t], rtol=1e-14, atol=1e-16)      # numpy's scalar vs array log differ by an ulp
+
+
 def test_solow_runner_history_and_autoreset(golden):
     g = golden("solow_runner")
     steps, E = g["raw_actions"].shape[:2]
