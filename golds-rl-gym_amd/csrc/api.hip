@@ -449,6 +449,13 @@ int grl_read_output(grl_handle *h, const char *which, void *host, size_t bytes) 
     if (need != bytes) return fail(h, GRL_E_SIZE, "grl_read_output: '" + w + "' needs " + std::to_string(need) + " bytes, got " + std::to_string(bytes));
     GRL_HIP(h, hipStreamSynchronize(h->stream));
     GRL_HIP(h, hipMemcpy(host, src, bytes, hipMemcpyDeviceToHost));
+    if (w == "done_list") {      // the device compacts finished envs in wave / workgroup arrival order: hand them out sorted
+        int32_t cnt = 0;
+        GRL_HIP(h, hipMemcpy(&cnt, o.done_count, 4, hipMemcpyDeviceToHost));
+        int32_t *ids = (int32_t *)host;
+        const size_t n = (size_t)cnt < bytes / 4 ? (size_t)cnt : bytes / 4;
+        std::sort(ids, ids + n);
+    }
     return GRL_OK;
 }
 

@@ -156,6 +156,9 @@ static int nalloc(grl_net *n, T **p, size_t count) {
     NET_HIP(n, hipMalloc((void **)p, count * sizeof(T)));
     n->allocs.push_back(*p);
     NET_HIP(n, hipMemsetAsync(*p, 0, count * sizeof(T), n->h->stream));
+    // allocations happen on whichever lane is current (a non-blocking stream) while other streams may be the first to touch the
+    // buffer (w2t / w3t are written on the main stream): finish the fill before anyone can see the pointer
+    NET_HIP(n, hipStreamSynchronize(n->h->stream));
     return GRL_OK;
 }
 

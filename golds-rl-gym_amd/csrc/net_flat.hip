@@ -430,6 +430,18 @@ int grl_fnet_set_optimizer_state(grl_fnet *n, const float *m_host, const float *
     return rc;
 }
 
+int grl_fnet_get_action_counter(grl_fnet *net, uint64_t *out) {
+    if (!net || !out) return GRL_E_INVALID;
+    *out = (uint64_t)net->act_counter;
+    return GRL_OK;
+}
+
+int grl_fnet_set_action_counter(grl_fnet *net, uint64_t value) {
+    if (!net) return GRL_E_INVALID;
+    net->act_counter = (unsigned long)value;
+    return GRL_OK;
+}
+
 static int fdownload(grl_fnet *net, int n, float *mu, float *sigma, float *vs) {
     const int A = net->cfg.num_actions;
     FNET_HIP(net, hipStreamSynchronize(net->h->stream));

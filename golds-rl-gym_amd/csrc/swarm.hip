@@ -39,6 +39,7 @@ struct SwarmLds {
     double en[SWARM_EPB][N_LOCUSTS];
     double meanx[SWARM_EPB];
     double rew[SWARM_EPB];
+    int dflag[SWARM_EPB];      // env id of a finished episode (or -1): folded into ONE atomicAdd per workgroup
 };
 
 constexpr double DT = 0.05, NOISE = 0.0001, WIND = 1.0, GRAV = -1.0, FATT = 0.5, LATT = 10.0;
@@ -234,9 +235,23 @@ __global__ __launch_bounds__(SWARM_TPB) void swarm_kernel(SwarmParams P) {
             P.reward64[env] = r;
             P.reward[env] = (float)r;
             P.done[env] = d ? 1 : 0;
-            if (d) {
-                int slot = atomicAdd(P.done_count, 1);
-                P.done_list[slot] = env;
+            L.dflag[el] = d ? env : -1;
+        } else if (j == 0) {
+            L.dflag[el] = -1;
+        }
+        // episode-done compaction (emulator_runner.py:128-132 resets exactly these): the workgroup's finished envs take ONE slot
+        // range with one atomicAdd (at a TimeLimit boundary every env of the batch finishes in the same launch); the order of
+        // the list across workgroups is arrival order, grl_read_output("done_list") sorts it
+        __syncthreads();
+        if (tid == 0) {
+            int n = 0;
+#pragma unroll
+            for (int e = 0; e < SWARM_EPB; ++e) n += L.dflag[e] >= 0 ? 1 : 0;
+            if (n) {
+                int slot = atomicAdd(P.done_count, n);
+#pragma unroll
+                for (int e = 0; e < SWARM_EPB; ++e)
+                    if (L.dflag[e] >= 0) P.done_list[slot++] = L.dflag[e];
             }
         }
     }

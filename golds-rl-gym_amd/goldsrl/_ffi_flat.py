@@ -23,6 +23,8 @@ FNET_SIGNATURES = {
     "grl_fnet_set_params": (C.c_int, [_P, _P, C.c_int64]),
     "grl_fnet_get_params": (C.c_int, [_P, _P, C.c_int64]),
     "grl_fnet_get_grads": (C.c_int, [_P, _P, C.c_int64]),
+    "grl_fnet_get_action_counter": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    "grl_fnet_set_action_counter": (C.c_int, [_P, C.c_uint64]),
     "grl_fnet_get_optimizer_state": (C.c_int, [_P, _P, _P, C.c_int64, C.POINTER(C.c_int64)]),
     "grl_fnet_set_optimizer_state": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64]),
     "grl_fnet_predict": (C.c_int, [_P, _I, _P, _P, _P, _P, _P]),
@@ -129,17 +131,27 @@ class FlatNet(object):
         m, v = np.ascontiguousarray(adam_m, np.float32), np.ascontiguousarray(adam_v, np.float32)
         self._check(self.lib.grl_fnet_set_optimizer_state(self.n, _ffi._ptr(m), _ffi._ptr(v), m.size, int(adam_step)))
 
+    def get_action_counter(self):
+        v = C.c_uint64(0)
+        self._check(self.lib.grl_fnet_get_action_counter(self.n, C.byref(v)))
+        return int(v.value)
+
+    def set_action_counter(self, value):
+        self._check(self.lib.grl_fnet_set_action_counter(self.n, int(value)))
+
     def save_checkpoint(self, path, **extra):
         """Flat-weights checkpoint (.npz): parameters in tf.trainable_variables() order, Adam state, caller's scalars."""
         st = self.get_optimizer_state()
-        np.savez(path, params=self.get_params(), adam_m=st["adam_m"], adam_v=st["adam_v"], adam_step=st["adam_step"],
+        np.savez(path, params=self.get_params(), adam_m=st["adam_m"], adam_v=st["adam_v"], adam_step=st["adam_step"], action_counter=self.get_action_counter(),
                  **{k: np.asarray(v) for k, v in extra.items()})
 
     def load_checkpoint(self, path):
         with np.load(path) as z:
             self.set_params(z["params"])
             self.set_optimizer_state(z["adam_m"], z["adam_v"], int(z["adam_step"]))
-            return {k: z[k] for k in z.files if k not in ("params", "adam_m", "adam_v", "adam_step")}
+            if "action_counter" in z.files:      # the action-noise stream continues where the saved run stopped
+                self.set_action_counter(int(z["action_counter"]))
+            return {k: z[k] for k in z.files if k not in ("params", "adam_m", "adam_v", "adam_step", "action_counter")}
 
     def _outs(self, n):
         A = self.cfg.num_actions

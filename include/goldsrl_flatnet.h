@@ -53,6 +53,9 @@ int grl_fnet_get_grads(grl_fnet *net, float *host, int64_t n);
 /* Adam moments + update count (flat-weights checkpoint, as grl_net_get/set_optimizer_state) */
 int grl_fnet_get_optimizer_state(grl_fnet *net, float *m_host, float *v_host, int64_t n, int64_t *step_out);
 int grl_fnet_set_optimizer_state(grl_fnet *net, const float *m_host, const float *v_host, int64_t n, int64_t step);
+/* draw counter of grl_fnet_rollout's action noise (as grl_net_get/set_action_counter) */
+int grl_fnet_get_action_counter(grl_fnet *net, uint64_t *out);
+int grl_fnet_set_action_counter(grl_fnet *net, uint64_t value);
 
 /* network.predict(states, histories) + the value head, on HOST arrays: states (n,S0), history (n,T,D),
  * outputs mu (n,A) sigma (n,A) vs (n,) (any may be NULL).  Synchronous. */

@@ -59,6 +59,10 @@ int grl_net_get_grads(grl_net *net, float *host, int64_t n);   /* flat gradient 
  * is disabled in its scripts). */
 int grl_net_get_optimizer_state(grl_net *net, float *m_host, float *v_host, int64_t n, int64_t *step_out);
 int grl_net_set_optimizer_state(grl_net *net, const float *m_host, const float *v_host, int64_t n, int64_t step);
+/* Counter of the action-noise draws of grl_net_rollout (one per rollout step; the generator is keyed by (seed, env id, counter)):
+ * part of a checkpoint, so that a resumed run continues the noise stream instead of replaying it from 0. */
+int grl_net_get_action_counter(grl_net *net, uint64_t *out);
+int grl_net_set_action_counter(grl_net *net, uint64_t value);
 
 /* network.predict(states) (policy_v_network.py:69-80) on the CURRENT observation of the Swarm
  * handle: B = 10*num_envs agent-samples in env-major order.  Outputs are HOST arrays (may be NULL):

@@ -186,6 +186,8 @@ def test_grid_paac_learner_runs_updates(tmp_path):
     learner2 = GridPAACLearner(nc2, ec2, args2, SwarmRunner, state_processor=None)
     learner2.train()
     assert learner2.global_step == 960 and learner2.network.net.get_optimizer_state()["adam_step"] == 3
+    # the checkpoint carries the action-noise draw counter: the resumed run continues the stream (2 + 1 updates x 5 steps)
+    assert learner.network.net.get_action_counter() == 10 and learner2.network.net.get_action_counter() == 15
 
 
 def test_flat_paac_learner_runs_updates():
