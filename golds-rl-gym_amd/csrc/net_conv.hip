@@ -28,11 +28,22 @@ enum : uint32_t { RS_ACTION = 16 };
 struct ConvOffsets {
     static constexpr long c1w = 0, c1b = c1w + 8 * 8 * 3 * 32, c2w = c1b + 32, c2b = c2w + 4 * 4 * 32 * 64, c3w = c2b + 64,
                           c3b = c3w + 3 * 3 * 64 * 64, d1w = c3b + 64, d1b = d1w + 3136 * 512, d2w = d1b + 512,
-                          d2b = d2w + 512 * 256, p1w = d2b + 256, p1b = p1w + 256 * 512, muw = p1b + 512, mub = muw + 1024,
-                          sgw = mub + 2, sgb = sgw + 1024, v1w = sgb + 2, v1b = v1w + 256 * 512, v2w = v1b + 512,
-                          v2b = v2w + 512 * 256, v3w = v2b + 256, v3b = v3w + 256, total = v3b + 1;
+                          d2b = d2w + 512 * 256, p1w = d2b + 256, p1b = p1w + 256 * 512, heads = p1b + 512;
 };
-static_assert(ConvOffsets::total == 2210213, "parameter count (SURVEY N1)");
+// everything behind pol1 depends on num_actions A (policy_v_network.py:40-43: mu / sigma are Dense(A) heads):
+//   mu_w[512,A] mu_b[A] sigma_w[512,A] sigma_b[A] v1_w v1_b v2_w v2_b v3_w[256,1] v3_b
+constexpr int GRL_MAX_ACTIONS = 4;
+struct HeadOff {
+    long muw, mub, sgw, sgb, v1w, v1b, v2w, v2b, v3w, v3b, total;
+    int A, dz;      // dz: floats per row of the heads' dZ scratch = [dz_mu(A) | dz_sigma(A) | dz_v | policy-loss term | critic-loss term], padded
+};
+static HeadOff head_offsets(int A) {
+    HeadOff o;
+    o.A = A; o.dz = 2 * A + 4;
+    o.muw = ConvOffsets::heads; o.mub = o.muw + 512L * A; o.sgw = o.mub + A; o.sgb = o.sgw + 512L * A; o.v1w = o.sgb + A;
+    o.v1b = o.v1w + 256 * 512; o.v2w = o.v1b + 512; o.v2b = o.v2w + 512 * 256; o.v3w = o.v2b + 256; o.v3b = o.v3w + 256; o.total = o.v3b + 1;
+    return o;
+}
 
 using GatherConv2 = ConvGather<9, 9, 2, 2, 0, 0, 4, 4, 32, 20, 20, false>;    // a1[n][20][20][32] -> (n*81, 512)
 using GatherConv2Relu = ConvGather<9, 9, 2, 2, 0, 0, 4, 4, 32, 20, 20, false, true>;   // relu(sraw) -> the same operand
@@ -101,6 +112,7 @@ struct grl_net : NetLane {
     float *w3t, *w2t;          // rearranged conv weights for the data gradients
     float *w3f;                // w3f[(tap,co)][ci] = W3[tap][ci][co] (slot product GEMM of conv3's forward)
     int shared_trunk;
+    grl::HeadOff ho;           // offsets of the head / value parameters for this net's num_actions
     int npad, ptiles, pslices;
     size_t slab_floats;
     float *stats;              // device: loss sums
@@ -236,9 +248,9 @@ __global__ void transpose_kernel(const float *__restrict__ src, int K, int N, fl
 
 // keep paramsT in step with params (after set_params, Adam, broadcast)
 static void refresh_transposes(grl_net *net) {
-    static const struct { long off; int K, N; } L[] = {
+    const struct { long off; int K, N; } L[] = {
         {ConvOffsets::c2w, 512, 64}, {ConvOffsets::c3w, 576, 64}, {ConvOffsets::d1w, 3136, 512}, {ConvOffsets::d2w, 512, 256},
-        {ConvOffsets::p1w, 256, 512}, {ConvOffsets::v1w, 256, 512}, {ConvOffsets::v2w, 512, 256}};
+        {ConvOffsets::p1w, 256, 512}, {net->ho.v1w, 256, 512}, {net->ho.v2w, 512, 256}};
     for (const auto &l : L)
         hipLaunchKernelGGL(transpose_kernel, dim3((l.N + 31) / 32, (l.K + 31) / 32), dim3(32, 8), 0, net->h->stream, net->params + l.off,
                            l.K, l.N, net->paramsT + l.off);
@@ -319,6 +331,55 @@ __global__ __launch_bounds__(256) void conv1_sparse_kernel(const uint8_t *__rest
     }
 }
 
+// Shared-trunk form of the same layer (net_shared.inc): ONE pre-activation image per env, written straight from registers.
+// A work item is (output pixel, 8 of the 32 channels): 1 600 items per env over 256 lanes (6.25 rounds instead of the 1.56 of a
+// lane per pixel), 8 accumulators per lane, and no 51 KB staging tile in LDS -- only the two 7 KB count grids, so ten workgroups
+// share a CU instead of two.  Same sums in the same order as conv1_sparse_kernel (bit-identical output).
+__global__ __launch_bounds__(256) void conv1_sparse_shared_kernel(const uint8_t *__restrict__ lbins, const uint8_t *__restrict__ abins,
+                                                                  const float *__restrict__ w1, const float *__restrict__ b1, int G,
+                                                                  float *__restrict__ sraw) {
+    __shared__ unsigned int cnt[2][7056 / 4 + 4];   // 84x84 byte counters per channel, packed 4 per word
+    const int env = blockIdx.x, tid = threadIdx.x;
+    for (int i = tid; i < 2 * (7056 / 4 + 4); i += 256) (&cnt[0][0])[i] = 0;
+    __syncthreads();
+    if (tid < 80) {
+        int bx = lbins[((size_t)env * 80 + tid) * 2], by = lbins[((size_t)env * 80 + tid) * 2 + 1];
+        if (bx != 255) { int idx = bx * G + by; atomicAdd(&cnt[0][idx >> 2], 1u << (8 * (idx & 3))); }
+    } else if (tid < 90) {
+        int a = tid - 80;
+        int bx = abins[((size_t)env * 10 + a) * 2], by = abins[((size_t)env * 10 + a) * 2 + 1];
+        if (bx != 255) { int idx = bx * G + by; atomicAdd(&cnt[1][idx >> 2], 1u << (8 * (idx & 3))); }
+    }
+    __syncthreads();
+    float4 *out = reinterpret_cast<float4 *>(sraw + (size_t)env * 12800);
+    for (int item = tid; item < 1600; item += 256) {
+        const int pix = item >> 2, c0 = (item & 3) * 8;
+        const int oy = pix / 20, ox = pix - oy * 20;
+        float acc[8];
+#pragma unroll
+        for (int co = 0; co < 8; ++co) acc[co] = b1[c0 + co];
+        for (int ky = 0; ky < 8; ++ky) {
+            const int rowbase = (4 * oy + ky) * G + 4 * ox;   // multiple of 4: G = 84
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                unsigned int w0 = cnt[c][rowbase >> 2], w1_ = cnt[c][(rowbase >> 2) + 1];
+                if ((w0 | w1_) == 0) continue;
+#pragma unroll
+                for (int kx = 0; kx < 8; ++kx) {
+                    unsigned int k = ((kx < 4 ? w0 : w1_) >> (8 * (kx & 3))) & 255u;
+                    if (k == 0) continue;
+                    float val = (float)((double)k / (c == 0 ? 80.0 : 10.0));      // state_processors.py:33
+                    const float *wp = w1 + ((ky * 8 + kx) * 3 + c) * 32 + c0;
+#pragma unroll
+                    for (int co = 0; co < 8; ++co) acc[co] += val * wp[co];
+                }
+            }
+        }
+        out[item * 2] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        out[item * 2 + 1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    }
+}
+
 // ------------------------------------------------------------------------------------------ heads
 // mu = tanh(p1 Wmu + b), sigma = sigmoid(p1 Wsg + b), vs = -scale*softplus(v2 Wv3 + b)
 // (policy_v_network.py:40-59).  One wave per sample row.
@@ -328,30 +389,43 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+template <int A>
 __global__ __launch_bounds__(256) void heads_forward_kernel(const float *__restrict__ p1, const float *__restrict__ v2,
-                                                            const float *__restrict__ params, int n, float scale,
+                                                            const float *__restrict__ params, HeadOff o, int n, float scale,
                                                             float *__restrict__ mu, float *__restrict__ sigma, float *__restrict__ vs) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= n) return;
-    const float *muw = params + ConvOffsets::muw, *sgw = params + ConvOffsets::sgw, *v3w = params + ConvOffsets::v3w;
-    float m0 = 0, m1 = 0, s0 = 0, s1 = 0, zv = 0;
+    const float *muw = params + o.muw, *sgw = params + o.sgw, *v3w = params + o.v3w;
+    float m[A], s[A], zv = 0;
+#pragma unroll
+    for (int a = 0; a < A; ++a) { m[a] = 0; s[a] = 0; }
     for (int k = lane; k < 512; k += 64) {
         float x = p1[(size_t)row * 512 + k];
-        m0 += x * muw[k * 2]; m1 += x * muw[k * 2 + 1];
-        s0 += x * sgw[k * 2]; s1 += x * sgw[k * 2 + 1];
+#pragma unroll
+        for (int a = 0; a < A; ++a) { m[a] += x * muw[k * A + a]; s[a] += x * sgw[k * A + a]; }
     }
     for (int k = lane; k < 256; k += 64) zv += v2[(size_t)row * 256 + k] * v3w[k];
-    m0 = wave_sum(m0); m1 = wave_sum(m1); s0 = wave_sum(s0); s1 = wave_sum(s1); zv = wave_sum(zv);
+#pragma unroll
+    for (int a = 0; a < A; ++a) { m[a] = wave_sum(m[a]); s[a] = wave_sum(s[a]); }
+    zv = wave_sum(zv);
     if (lane == 0) {
-        m0 += params[ConvOffsets::mub]; m1 += params[ConvOffsets::mub + 1];
-        s0 += params[ConvOffsets::sgb]; s1 += params[ConvOffsets::sgb + 1];
-        zv += params[ConvOffsets::v3b];
-        mu[(size_t)row * 2] = tanhf(m0); mu[(size_t)row * 2 + 1] = tanhf(m1);
-        sigma[(size_t)row * 2] = 1.0f / (1.0f + expf(-s0)); sigma[(size_t)row * 2 + 1] = 1.0f / (1.0f + expf(-s1));
+#pragma unroll
+        for (int a = 0; a < A; ++a) {
+            mu[(size_t)row * A + a] = tanhf(m[a] + params[o.mub + a]);
+            sigma[(size_t)row * A + a] = 1.0f / (1.0f + expf(-(s[a] + params[o.sgb + a])));
+        }
+        zv += params[o.v3b];
         float sp = zv > 20.f ? zv : log1pf(expf(zv));
         vs[row] = -scale * sp;
     }
 }
+#define GRL_HEADS_DISPATCH(A_, CALL)                                  \
+    switch (A_) {                                                     \
+        case 1: { constexpr int kA = 1; CALL; } break;                \
+        case 2: { constexpr int kA = 2; CALL; } break;                \
+        case 3: { constexpr int kA = 3; CALL; } break;                \
+        default: { constexpr int kA = 4; CALL; } break;               \
+    }
 
 // a = mu + sigma * N(0,1) (paac.py:418), then SwarmRunner.transform_actions_for_env (emulator_runner.py:113-118)
 __global__ void sample_actions_kernel(const float *__restrict__ mu, const float *__restrict__ sigma, int n, uint64_t seed,
@@ -464,10 +538,11 @@ static int forward_chunk(grl_net *net, const uint8_t *lb, const uint8_t *ab, con
     if (!net->shared_trunk) dense(net->a3, 3136, PT + ConvOffsets::d1w, P + ConvOffsets::d1b, 512, net->d1);
     dense(net->d1, 512, PT + ConvOffsets::d2w, P + ConvOffsets::d2b, 256, net->d2);
     dense(net->d2, 256, PT + ConvOffsets::p1w, P + ConvOffsets::p1b, 512, net->p1);
-    dense(net->d2, 256, PT + ConvOffsets::v1w, P + ConvOffsets::v1b, 512, net->v1);
-    dense(net->v1, 512, PT + ConvOffsets::v2w, P + ConvOffsets::v2b, 256, net->v2);
+    dense(net->d2, 256, PT + net->ho.v1w, P + net->ho.v1b, 512, net->v1);
+    dense(net->v1, 512, PT + net->ho.v2w, P + net->ho.v2b, 256, net->v2);
     }
-    hipLaunchKernelGGL(heads_forward_kernel, dim3((n + 3) / 4), dim3(256), 0, st, net->p1, net->v2, P, n, net->cfg.scale, mu, sigma, vs);
+    GRL_HEADS_DISPATCH(net->ho.A, hipLaunchKernelGGL(heads_forward_kernel<kA>, dim3((n + 3) / 4), dim3(256), 0, st, net->p1, net->v2, P, net->ho, n,
+                                                      net->cfg.scale, mu, sigma, vs));
     NET_HIP(net, hipGetLastError());
     return GRL_OK;
 }
@@ -484,8 +559,8 @@ static int forward_all(grl_net *net, const uint8_t *lb, const uint8_t *ab, const
         use_lane(net, (e0 / ce) % nl);      // independent chunks alternate between the two streams
         net->last_lane = net->cur_lane;
         bind_activations(net, slot0 < 0 ? -1 : slot0 + e0 / ce);
-        rc = forward_chunk(net, lb + (size_t)e0 * 160, ab + (size_t)e0 * 20, pos + (size_t)e0 * 20, ne, mu + (size_t)e0 * 20,
-                           sigma + (size_t)e0 * 20, vs + (size_t)e0 * 10);
+        rc = forward_chunk(net, lb + (size_t)e0 * 160, ab + (size_t)e0 * 20, pos + (size_t)e0 * 20, ne,
+                           mu + (size_t)e0 * 10 * net->ho.A, sigma + (size_t)e0 * 10 * net->ho.A, vs + (size_t)e0 * 10);
         if (rc) { (void)lanes_join(net); return rc; }
     }
     return lanes_join(net);
@@ -496,7 +571,7 @@ static int alloc_lane_forward(grl_net *n) {
     const size_t c = n->chunk;
     int rc = GRL_OK;
     auto A = [&](float **p, size_t cnt) { if (rc == GRL_OK) rc = nalloc(n, p, cnt); };
-    A(&n->grads, ConvOffsets::total);
+    A(&n->grads, n->ho.total);
     A(&n->a2, c * 5184); A(&n->d1, c * 512); A(&n->d2, c * 256); A(&n->p1, c * 512); A(&n->v1, c * 512); A(&n->v2, c * 256);
     if (!n->shared_trunk) { A(&n->a1, c * 12800); A(&n->a3, c * 3136); }       // per-agent tensors the shared evaluation never forms
     A(&n->sraw, (c / 10) * 12800); A(&n->z2sh, (c / 10) * 5184);
@@ -529,8 +604,8 @@ static int ensure_tmp_obs(grl_net *net, int n_envs) {
     if ((rc = nalloc(net, &net->tmp_ab, (size_t)n_envs * 20))) return rc;
     if ((rc = nalloc(net, &net->tmp_pos, (size_t)n_envs * 20))) return rc;
     float *m, *s, *v;
-    if ((rc = nalloc(net, &m, (size_t)n_envs * 20))) return rc;
-    if ((rc = nalloc(net, &s, (size_t)n_envs * 20))) return rc;
+    if ((rc = nalloc(net, &m, (size_t)n_envs * 10 * net->ho.A))) return rc;
+    if ((rc = nalloc(net, &s, (size_t)n_envs * 10 * net->ho.A))) return rc;
     if ((rc = nalloc(net, &v, (size_t)n_envs * 10))) return rc;
     net->mu = m; net->sigma = s; net->vs = v;
     net->tmp_envs = n_envs;
@@ -553,6 +628,7 @@ int grl_net_config_default(int32_t kind, grl_net_config *cfg) {
     cfg->entropy_beta = 0.02f;    // :103
     cfg->clip_norm = 40.f;        // :104
     cfg->gamma = 0.99f;           // :106
+    cfg->num_actions = 2;         // SwarmEnvironmentCreator.num_actions (environment_creator.py:17-20)
     return GRL_OK;
 }
 
@@ -565,9 +641,12 @@ int grl_net_create(grl_handle *h, const grl_net_config *cfg, grl_net **out) {
         return fail(h, GRL_E_INVALID, "grl_net_create: the conv net needs a Swarm handle with grid_size 84 (84x84x3 input)");
     if (cfg->max_chunk_samples < 10 || cfg->max_chunk_samples % 10 || cfg->max_chunk_samples > 131072)
         return fail(h, GRL_E_INVALID, "grl_net_create: max_chunk_samples must be a multiple of 10 in 10..131072");
+    if (cfg->num_actions < 1 || cfg->num_actions > GRL_MAX_ACTIONS)
+        return fail(h, GRL_E_INVALID, "grl_net_create: num_actions must be in 1..4");
     hipSetDevice(h->cfg.device_id);
     grl_net *n = new grl_net();
     n->h = h; n->cfg = *cfg; n->chunk = cfg->max_chunk_samples; n->adam_t = 0;
+    n->ho = head_offsets(cfg->num_actions);
     n->T = 0; n->B = 0; n->tmp_envs = 0; n->act_counter = 0; n->prof_on = false; n->prof_used = 0; n->prof_flops = 0; n->last_n = 0; n->prof_tag_cur = 0;
     n->ro_lb = nullptr; n->slab_floats = 0; n->w3t = n->w2t = nullptr;
     n->mu = n->sigma = n->vs = nullptr;
@@ -583,7 +662,7 @@ int grl_net_create(grl_handle *h, const grl_net_config *cfg, grl_net **out) {
     n->npad = (int)((c + 255) / 256 * 256);
     int rc = GRL_OK;
     auto A = [&](float **p, size_t cnt) { if (rc == GRL_OK) rc = nalloc(n, p, cnt); };
-    A(&n->params, ConvOffsets::total); A(&n->paramsT, ConvOffsets::total); A(&n->adam_m, ConvOffsets::total); A(&n->adam_v, ConvOffsets::total);
+    A(&n->params, n->ho.total); A(&n->paramsT, n->ho.total); A(&n->adam_m, n->ho.total); A(&n->adam_v, n->ho.total);
     A(&n->w3f, 576 * 64); A(&n->stats, 16);
     int nlanes = (cfg->reserved & GRL_NET_F_SINGLE_STREAM) ? 1 : 4;      // measured at 32 768 envs: 1.41 / 1.22 / 1.16 / 1.13 / 1.14 s per update with 1 / 2 / 3 / 4 / 8
     if (const char *env = getenv("GRL_NET_LANES")) { int v = atoi(env); if (v >= 1 && v <= GRL_MAX_LANES) nlanes = v; }      // tuning knob
@@ -637,11 +716,11 @@ int grl_net_destroy(grl_net *n) {
 }
 
 const char *grl_net_last_error(const grl_net *n) { return n ? n->err.c_str() : ""; }
-int64_t grl_net_num_params(const grl_net *n) { return n ? ConvOffsets::total : 0; }
+int64_t grl_net_num_params(const grl_net *n) { return n ? n->ho.total : 0; }
 
 int grl_net_set_params(grl_net *n, const float *host, int64_t cnt) {
     if (!n || !host) return GRL_E_INVALID;
-    if (cnt != ConvOffsets::total) return nfail(n, GRL_E_SIZE, "grl_net_set_params: expected " + std::to_string((long)ConvOffsets::total) + " floats");
+    if (cnt != n->ho.total) return nfail(n, GRL_E_SIZE, "grl_net_set_params: expected " + std::to_string((long)n->ho.total) + " floats");
     hipSetDevice(n->h->cfg.device_id);
     NET_HIP(n, hipStreamSynchronize(n->h->stream));
     NET_HIP(n, hipMemcpy(n->params, host, cnt * 4, hipMemcpyHostToDevice));
@@ -653,7 +732,7 @@ int grl_net_set_params(grl_net *n, const float *host, int64_t cnt) {
 
 static int get_flat(grl_net *n, const float *src, float *host, int64_t cnt) {
     if (!n || !host) return GRL_E_INVALID;
-    if (cnt != ConvOffsets::total) return nfail(n, GRL_E_SIZE, "expected " + std::to_string((long)ConvOffsets::total) + " floats");
+    if (cnt != n->ho.total) return nfail(n, GRL_E_SIZE, "expected " + std::to_string((long)n->ho.total) + " floats");
     hipSetDevice(n->h->cfg.device_id);
     NET_HIP(n, hipStreamSynchronize(n->h->stream));
     NET_HIP(n, hipMemcpy(host, src, cnt * 4, hipMemcpyDeviceToHost));
@@ -672,7 +751,7 @@ int grl_net_get_optimizer_state(grl_net *n, float *m_host, float *v_host, int64_
 
 int grl_net_set_optimizer_state(grl_net *n, const float *m_host, const float *v_host, int64_t cnt, int64_t step) {
     if (!n || !m_host || !v_host || step < 0) return GRL_E_INVALID;
-    if (cnt != ConvOffsets::total) return nfail(n, GRL_E_SIZE, "grl_net_set_optimizer_state: expected " + std::to_string((long)ConvOffsets::total) + " floats");
+    if (cnt != n->ho.total) return nfail(n, GRL_E_SIZE, "grl_net_set_optimizer_state: expected " + std::to_string((long)n->ho.total) + " floats");
     hipSetDevice(n->h->cfg.device_id);
     NET_HIP(n, hipStreamSynchronize(n->h->stream));
     NET_HIP(n, hipMemcpy(n->adam_m, m_host, cnt * 4, hipMemcpyHostToDevice));
@@ -683,8 +762,8 @@ int grl_net_set_optimizer_state(grl_net *n, const float *m_host, const float *v_
 
 static int download_heads(grl_net *n, int B, float *mu_host, float *sigma_host, float *vs_host) {
     NET_HIP(n, hipStreamSynchronize(n->h->stream));
-    if (mu_host) NET_HIP(n, hipMemcpy(mu_host, n->mu, (size_t)B * 8, hipMemcpyDeviceToHost));
-    if (sigma_host) NET_HIP(n, hipMemcpy(sigma_host, n->sigma, (size_t)B * 8, hipMemcpyDeviceToHost));
+    if (mu_host) NET_HIP(n, hipMemcpy(mu_host, n->mu, (size_t)B * n->ho.A * 4, hipMemcpyDeviceToHost));
+    if (sigma_host) NET_HIP(n, hipMemcpy(sigma_host, n->sigma, (size_t)B * n->ho.A * 4, hipMemcpyDeviceToHost));
     if (vs_host) NET_HIP(n, hipMemcpy(vs_host, n->vs, (size_t)B * 4, hipMemcpyDeviceToHost));
     return GRL_OK;
 }

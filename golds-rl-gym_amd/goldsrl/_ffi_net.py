@@ -10,7 +10,8 @@ _P, _I, _F, _SZ = C.c_void_p, C.c_int32, C.c_float, C.c_size_t
 
 class GrlNetConfig(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("kind", C.c_int32), ("max_chunk_samples", C.c_int32), ("reserved", C.c_int32),
-                ("scale", C.c_float), ("entropy_beta", C.c_float), ("clip_norm", C.c_float), ("gamma", C.c_float)]
+                ("scale", C.c_float), ("entropy_beta", C.c_float), ("clip_norm", C.c_float), ("gamma", C.c_float),
+                ("num_actions", C.c_int32), ("reserved2", C.c_int32)]
 
 
 NET_SIGNATURES = {
@@ -50,20 +51,25 @@ NET_CONV_SINGLE_AGENT = 0
 
 # (name, shape) in flat-vector order == tf.trainable_variables() creation order
 # (reference fed_gym/agents/paac/policy_v_network.py:14-59)
-CONV_PARAM_SHAPES = [
-    ("conv1_w", (8, 8, 3, 32)), ("conv1_b", (32,)), ("conv2_w", (4, 4, 32, 64)), ("conv2_b", (64,)),
-    ("conv3_w", (3, 3, 64, 64)), ("conv3_b", (64,)), ("dense1_w", (3136, 512)), ("dense1_b", (512,)),
-    ("dense2_w", (512, 256)), ("dense2_b", (256,)), ("pol1_w", (256, 512)), ("pol1_b", (512,)),
-    ("mu_w", (512, 2)), ("mu_b", (2,)), ("sigma_w", (512, 2)), ("sigma_b", (2,)),
-    ("v1_w", (256, 512)), ("v1_b", (512,)), ("v2_w", (512, 256)), ("v2_b", (256,)), ("v3_w", (256, 1)), ("v3_b", (1,)),
-]
+def conv_param_shapes(num_actions=2):
+    A = int(num_actions)
+    return [
+        ("conv1_w", (8, 8, 3, 32)), ("conv1_b", (32,)), ("conv2_w", (4, 4, 32, 64)), ("conv2_b", (64,)),
+        ("conv3_w", (3, 3, 64, 64)), ("conv3_b", (64,)), ("dense1_w", (3136, 512)), ("dense1_b", (512,)),
+        ("dense2_w", (512, 256)), ("dense2_b", (256,)), ("pol1_w", (256, 512)), ("pol1_b", (512,)),
+        ("mu_w", (512, A)), ("mu_b", (A,)), ("sigma_w", (512, A)), ("sigma_b", (A,)),
+        ("v1_w", (256, 512)), ("v1_b", (512,)), ("v2_w", (512, 256)), ("v2_b", (256,)), ("v3_w", (256, 1)), ("v3_b", (1,)),
+    ]
 
 
-def glorot_uniform_flat(seed=3):
+CONV_PARAM_SHAPES = conv_param_shapes(2)      # train_paac_conv.py: SwarmEnvironmentCreator.num_actions = 2
+
+
+def glorot_uniform_flat(seed=3, num_actions=2):
     """tf.layers defaults: glorot-uniform kernels, zero biases -> flat float32 vector."""
     rng = np.random.RandomState(seed)
     parts = []
-    for name, shape in CONV_PARAM_SHAPES:
+    for name, shape in conv_param_shapes(num_actions):
         if name.endswith("_w"):
             if len(shape) == 2:
                 fan_in, fan_out = shape
@@ -162,8 +168,8 @@ class ConvNet(object):
             return {k: z[k] for k in z.files if k not in ("params", "adam_m", "adam_v", "adam_step", "action_counter")}
 
     def predict(self):
-        B = self.eng.E * 10
-        mu, sg, vs = np.empty((B, 2), np.float32), np.empty((B, 2), np.float32), np.empty(B, np.float32)
+        B, A = self.eng.E * 10, int(self.cfg.num_actions)
+        mu, sg, vs = np.empty((B, A), np.float32), np.empty((B, A), np.float32), np.empty(B, np.float32)
         self._check(self.lib.grl_net_predict(self.n, _ffi._ptr(mu), _ffi._ptr(sg), _ffi._ptr(vs)))
         return {"mu": mu, "sigma": sg, "vs": vs}
 
@@ -171,8 +177,8 @@ class ConvNet(object):
         lb = np.ascontiguousarray(locust_bins, np.uint8); ab = np.ascontiguousarray(agent_bins, np.uint8)
         ps = np.ascontiguousarray(positions, np.uint8)
         ne = lb.shape[0]
-        B = ne * 10
-        mu, sg, vs = np.empty((B, 2), np.float32), np.empty((B, 2), np.float32), np.empty(B, np.float32)
+        B, A = ne * 10, int(self.cfg.num_actions)
+        mu, sg, vs = np.empty((B, A), np.float32), np.empty((B, A), np.float32), np.empty(B, np.float32)
         self._check(self.lib.grl_net_predict_obs(self.n, ne, _ffi._ptr(lb), _ffi._ptr(ab), _ffi._ptr(ps), _ffi._ptr(mu),
                                                  _ffi._ptr(sg), _ffi._ptr(vs)))
         return {"mu": mu, "sigma": sg, "vs": vs}
@@ -182,6 +188,8 @@ class ConvNet(object):
         ps = np.ascontiguousarray(positions, np.uint8)
         a = np.ascontiguousarray(actions, np.float32); adv = np.ascontiguousarray(advantages, np.float32)
         y = np.ascontiguousarray(critic_target, np.float32)
+        if a.shape != (lb.shape[0] * 10, int(self.cfg.num_actions)):
+            raise ValueError("train_obs: actions must be (%d, %d), got %s" % (lb.shape[0] * 10, self.cfg.num_actions, a.shape))
         stats = np.zeros(4, np.float32)
         self._check(self.lib.grl_net_train_obs(self.n, lb.shape[0], _ffi._ptr(lb), _ffi._ptr(ab), _ffi._ptr(ps), _ffi._ptr(a),
                                                _ffi._ptr(adv), _ffi._ptr(y), lr, 1 if apply_update else 0, _ffi._ptr(stats)))

@@ -18,8 +18,10 @@ class ConvSingleAgentPolicyNetwork(object):
         self.scale = conf['scale']
         self.height, self.width, self.channels = conf['height'], conf['width'], conf['channels']
         self.fc_hidden = 256
-        if (self.height, self.width, self.channels, self.num_actions) != (84, 84, 3, 2):
-            raise ValueError("the device net is built for 84x84x3 inputs and 2 actions (train_paac_conv.py defaults)")
+        if (self.height, self.width, self.channels) != (84, 84, 3):
+            raise ValueError("the device net is built for 84x84x3 inputs (train_paac_conv.py defaults; the conv geometry is compiled in)")
+        if not 1 <= self.num_actions <= 4:
+            raise ValueError("num_actions must be in 1..4 (the mu / sigma heads are Dense(num_actions), policy_v_network.py:40-43)")
         if self.clip_norm_type not in ('global', 'ignore'):
             # 'local' is broken in the reference too (actor_learner.py:60-61 iterates (grad, var) tuples)
             raise Exception('Norm type not recognized')
@@ -28,8 +30,8 @@ class ConvSingleAgentPolicyNetwork(object):
     def bind(self, engine, gamma=0.99, seed=3, chunk=40960):
         clip = self.clip_norm if self.clip_norm_type == 'global' else 0.0
         self.net = _ffi_net.ConvNet(engine, max_chunk_samples=min(chunk, engine.E * 10), scale=self.scale,
-                                    entropy_beta=self.entropy_beta, clip_norm=clip, gamma=gamma)
-        self.net.set_params(_ffi_net.glorot_uniform_flat(seed))
+                                    entropy_beta=self.entropy_beta, clip_norm=clip, gamma=gamma, num_actions=self.num_actions)
+        self.net.set_params(_ffi_net.glorot_uniform_flat(seed, self.num_actions))
         return self
 
     def predict(self, states=None, session=None):

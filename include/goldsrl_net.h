@@ -8,8 +8,8 @@
  * Conventions as in goldsrl.h.  A net is bound to the device/stream of the grl_handle it was
  * created on.  Parameters are one flat float32 vector in tf.trainable_variables() creation order:
  *   conv1_w[8,8,3,32] conv1_b conv2_w[4,4,32,64] conv2_b conv3_w[3,3,64,64] conv3_b dense1_w[3136,512]
- *   dense1_b dense2_w[512,256] dense2_b pol1_w[256,512] pol1_b mu_w[512,2] mu_b sigma_w[512,2] sigma_b
- *   v1_w[256,512] v1_b v2_w[512,256] v2_b v3_w[256,1] v3_b                          (2 210 213 floats)
+ *   dense1_b dense2_w[512,256] dense2_b pol1_w[256,512] pol1_b mu_w[512,A] mu_b[A] sigma_w[512,A] sigma_b[A]
+ *   v1_w[256,512] v1_b v2_w[512,256] v2_b v3_w[256,1] v3_b          (2 210 213 floats at A = num_actions = 2)
  */
 #ifndef GOLDSRL_NET_H
 #define GOLDSRL_NET_H
@@ -42,6 +42,10 @@ typedef struct grl_net_config {
     float entropy_beta;        /* conf['entropy_regularisation_strength'] (0.02) */
     float clip_norm;           /* --clip_norm (40), clip_norm_type 'global'; <= 0 means 'ignore' */
     float gamma;               /* --gamma (0.99) */
+    int32_t num_actions;       /* conf['num_actions'] (policy_v_network.py:10,40-43): width A of the mu / sigma heads, 1..4; default 2
+                                * (SwarmEnvironmentCreator.num_actions).  predict / train on supplied samples work for any A;
+                                * grl_net_rollout needs A = 2 because SwarmEnv.step takes (10, 2) actions. */
+    int32_t reserved2;
 } grl_net_config;
 
 typedef struct grl_net grl_net;
@@ -66,7 +70,7 @@ int grl_net_set_action_counter(grl_net *net, uint64_t value);
 
 /* network.predict(states) (policy_v_network.py:69-80) on the CURRENT observation of the Swarm
  * handle: B = 10*num_envs agent-samples in env-major order.  Outputs are HOST arrays (may be NULL):
- * mu (B,2) sigma (B,2) vs (B,).  Synchronous. */
+ * mu (B,A) sigma (B,A) vs (B,).  Synchronous. */
 int grl_net_predict(grl_net *net, float *mu_host, float *sigma_host, float *vs_host);
 /* Same on caller-supplied compact observations (host): locust_bins (n_envs,80,2) agent_bins (n_envs,10,2)
  * positions (n_envs,10,2), all uint8 as in grl_out_ptrs. */
@@ -93,7 +97,7 @@ int grl_net_train_rollout_grads(grl_net *net, float *stats_host);
 int grl_net_set_grads(grl_net *net, const float *host, int64_t n);
 int grl_net_apply_grads(grl_net *net, float lr, float grad_scale, float *stats_host);
 /* Gradient step on caller-supplied samples (tests; network.loss feed of paac.py:374-387):
- * compact observations for n_envs envs (n = 10*n_envs samples), actions (n,2), advantages (n,)
+ * compact observations for n_envs envs (n = 10*n_envs samples), actions (n,A), advantages (n,)
  * ALREADY divided by scale, critic_target (n,).  apply_update=0 only computes gradients. */
 int grl_net_train_obs(grl_net *net, int32_t n_envs, const uint8_t *locust_bins, const uint8_t *agent_bins,
                       const uint8_t *positions, const float *actions, const float *advantages,

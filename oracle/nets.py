@@ -45,6 +45,11 @@ def glorot_uniform(rng, shape):
     return rng.uniform(-lim, lim, size=shape)
 
 
+def conv_param_shapes(num_actions=2):
+    """CONV_PARAM_SHAPES with Dense(num_actions) mu / sigma heads (policy_v_network.py:40-43)."""
+    return [(n, (s[0], num_actions) if n in ("mu_w", "sigma_w") else ((num_actions,) if n in ("mu_b", "sigma_b") else s)) for n, s in CONV_PARAM_SHAPES]
+
+
 def conv_init(seed=3):
     rng = np.random.RandomState(seed)
     return {n: (glorot_uniform(rng, s) if n.endswith("_w") else np.zeros(s)) for n, s in CONV_PARAM_SHAPES}

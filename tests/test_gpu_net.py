@@ -109,6 +109,67 @@ def test_conv_gradients_match_oracle(flags):
     assert np.array_equal(first, net.get_grads())
 
 
+@pytest.mark.parametrize("A", [1, 3, 4])
+def test_num_actions_is_a_parameter_of_the_heads(A):
+    """ConvSingleAgentPolicyNetwork takes conf['num_actions'] (policy_v_network.py:10,40-43; the reference's own shape test
+    builds it with 3 actions, scale 1, entropy 0: tests/estimators_tests.py:24-76).  Shapes, forward and every gradient against
+    the float64 oracle, one clipped Adam step, and the loud refusal to drive SwarmEnv (2-component actions) with it."""
+    from goldsrl import _ffi, _ffi_net
+    from goldsrl.agents.paac.policy_v_network import ConvSingleAgentPolicyNetwork
+    E = 5
+    eng = _ffi.Engine(_ffi.ENV_SWARM, E, seed=11)
+    eng.reset()
+    conf = {'name': 'test_conv_network', 'num_actions': A, 'clip_norm': 40., 'clip_norm_type': 'global', 'device': '/cpu:0',
+            'static_size': None, 'n_agents': 10, 'entropy_regularisation_strength': 0., 'scale': 1., 'height': 84, 'width': 84,
+            'channels': 3, 'filters': 5, 'conv_layers': 2}
+    est = ConvSingleAgentPolicyNetwork(conf).bind(eng, chunk=30)
+    net = est.net
+    shapes = NN.conv_param_shapes(A)
+    assert [tuple(x) for x in _ffi_net.conv_param_shapes(A)] == [tuple(x) for x in shapes]
+    assert net.num_params == sum(int(np.prod(sh)) for _, sh in shapes) == 2210213 + (A - 2) * 1026
+    rng = np.random.RandomState(A)
+    flat = _ffi_net.glorot_uniform_flat(3, A).astype(np.float64)
+    p = NN.unflatten_params(flat, shapes)
+    for k in p:
+        if k.endswith("_b"):
+            p[k] = rng.normal(size=p[k].shape) * 0.05
+    flat = NN.flatten_params(p, shapes).astype(np.float32)
+    net.set_params(flat)
+    p = NN.unflatten_params(flat.astype(np.float64), shapes)
+    lb, ab, pos = eng.read("locust_bins"), eng.read("agent_bins"), eng.read("positions")
+    states = []
+    for e in range(E):
+        l = lb[e].astype(int); a = ab[e].astype(int)
+        l[l[:, 0] == 255] = -1; a[a[:, 0] == 255] = -1
+        states.append(O.swarm_local_states(O.swarm_grid_from_compact(l, a, 84), pos[e]))
+    states = np.concatenate(states).astype(np.float32).astype(np.float64)
+    out = est.predict()
+    n = E * 10
+    assert out["mu"].shape == (n, A) and out["sigma"].shape == (n, A) and out["vs"].shape == (n,)      # estimators_tests.py:72-76
+    mu, sigma, vs = NN.conv_forward(p, states, 1.0)
+    np.testing.assert_allclose(out["mu"], mu, rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(out["sigma"], sigma, rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(out["vs"], vs, rtol=2e-5, atol=1e-5)
+    act = rng.uniform(size=(n, A)).astype(np.float32)
+    adv, y = np.ones(n, np.float32), np.zeros(n, np.float32)                                            # the reference test's feed
+    stats = net.train_obs(lb, ab, pos, act, adv, y, lr=0.0, apply_update=False)
+    loss, pl, cl, g, _ = NN.conv_loss_and_grads(p, states, act.astype(np.float64), adv.astype(np.float64), y.astype(np.float64), 0.0, 1.0)
+    np.testing.assert_allclose([stats["loss"], stats["policy_loss"], stats["critic_loss_mean"]], [loss, pl, cl], rtol=1e-4, atol=1e-6)
+    got = NN.unflatten_params(net.get_grads().astype(np.float64), shapes)
+    for name, _ in shapes:
+        err = np.abs(got[name] - g[name]).max() / (np.abs(g[name]).max() + 1e-12)
+        assert err < 2e-4, (name, err)
+    gf = NN.flatten_params(g, shapes)
+    np.testing.assert_allclose(stats["global_norm"], np.sqrt((gf ** 2).sum()), rtol=1e-4)
+    net.train_obs(lb, ab, pos, act, adv, y, lr=1e-3, apply_update=True)
+    clipped, _ = NN.clip_by_global_norm(gf, 40.0)
+    ref, _, _ = NN.adam_step(flat.astype(np.float64), clipped, np.zeros_like(gf), np.zeros_like(gf), 1, 1e-3)
+    assert np.abs(net.get_params() - ref).max() <= 0.05 * 1e-3
+    with pytest.raises(_ffi.GrlError, match="num_actions"):
+        net.rollout(2, 0)
+    net.close(); eng.close()
+
+
 def test_adam_step_with_global_norm_clip_matches_oracle():
     E = 4
     eng, net, p, states, obs = _setup(E)
