@@ -253,10 +253,14 @@ def measure_swarm(args, ranks, E, T, want_roofline, label):
     for _ in range(args.warmup):
         roll.run()
     barrier()
-    eng.profile_enable(True)       # HIP events around the env step kernel only (it runs alone on the handle's stream)
     elapsed = timed(roll.run, eng.wait, args.steps)
     ranks.barrier()
     elapsed = ranks.max(elapsed)
+    # env step kernel alone (roofline_env_step): in the conv rollout every chunk's step overlaps other chunks' kernels and has no
+    # clean duration, so it is timed here on whole-batch launches of a short random-policy rollout (HIP events on the handle's stream)
+    probe = RandomPolicyRollout(eng, 4) if args.policy == "conv" else roll
+    eng.profile_enable(True)
+    probe.run(); eng.wait()
     env_launches, env_kernel_ms = eng.profile_read()
     eng.profile_enable(False)
     res = {"eng": eng, "roll": roll, "net": net, "exchange": exchange, "elapsed": elapsed, "E": E,

@@ -108,10 +108,10 @@ static int action_cols(const grl_handle *h) {
 }
 
 // R6 (paac.py:142-157, 331-349): one lane per env; finished episodes are compacted with a wave ballot + one atomicAdd per wave
-__global__ void episodes_account_kernel(const float *__restrict__ reward, const uint8_t *__restrict__ done, int E,
+__global__ void episodes_account_kernel(const float *__restrict__ reward, const uint8_t *__restrict__ done, int env_base, int E,
                                         double *__restrict__ total, int32_t *__restrict__ len, int64_t *__restrict__ steps,
                                         grl_episode_record *__restrict__ rec, int32_t *__restrict__ count, int cap) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int e = env_base + blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = e < E;
     double t = 0.0;
     int32_t l = 0;
@@ -142,10 +142,11 @@ __global__ void episodes_account_kernel(const float *__restrict__ reward, const 
     if (active) { total[e] = t; len[e] = l; steps[e] = s; }
 }
 
-int episodes_launch_account(grl_handle *h) {
+int episodes_launch_account(grl_handle *h, int env_base, int count) {
     if (!h->ep_total) return GRL_OK;
-    hipLaunchKernelGGL(episodes_account_kernel, dim3((h->E + 255) / 256), dim3(256), 0, h->stream, h->reward, h->done, h->E, h->ep_total,
-                       h->ep_len, h->ep_steps, h->ep_rec, h->ep_count, h->ep_capacity);
+    if (count < 0) count = h->E - env_base;
+    hipLaunchKernelGGL(episodes_account_kernel, dim3((count + 255) / 256), dim3(256), 0, h->stream, h->reward, h->done, env_base,
+                       env_base + count, h->ep_total, h->ep_len, h->ep_steps, h->ep_rec, h->ep_count, h->ep_capacity);
     GRL_HIP(h, hipGetLastError());
     return GRL_OK;
 }
@@ -243,7 +244,7 @@ int grl_create(const grl_config *cfg, grl_handle **out) {
     };
     h->actions_elems = E * action_cols(h);
     if ((rc = dm((void **)&h->elapsed, E * 4)) || (rc = dm((void **)&h->episode, E * 4)) || (rc = dm((void **)&h->reward, E * 4)) ||
-        (rc = dm((void **)&h->done, E)) || (rc = dm((void **)&h->done_list, E * 4)) || (rc = dm((void **)&h->done_count, 4)) ||
+        (rc = dm((void **)&h->done, E)) || (rc = dm((void **)&h->done_list, E * 4)) || (rc = dm((void **)&h->done_count, 16 * 4)) ||
         (rc = dm((void **)&h->err_flag, 4)) || (rc = dm((void **)&h->actions, h->actions_elems * 4)))
         return bail(rc);
     switch (cfg->env_kind) {

@@ -428,10 +428,11 @@ __global__ __launch_bounds__(256) void heads_forward_kernel(const float *__restr
     }
 
 // a = mu + sigma * N(0,1) (paac.py:418), then SwarmRunner.transform_actions_for_env (emulator_runner.py:113-118)
-__global__ void sample_actions_kernel(const float *__restrict__ mu, const float *__restrict__ sigma, int n, uint64_t seed,
+__global__ void sample_actions_kernel(const float *__restrict__ mu, const float *__restrict__ sigma, int i0, int n, uint64_t seed,
                                       uint32_t env_off, uint32_t counter, float *__restrict__ raw, float *__restrict__ envact) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;      // samples [i0, i0 + n) of the batch
     if (i >= n) return;
+    i += i0;
     int env = i / 10, a = i - env * 10;
     double e0, e1;
     normal_pair(rng_block(seed, (uint32_t)env + env_off, counter, RS_ACTION, a), e0, e1);

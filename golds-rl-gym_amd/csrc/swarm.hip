@@ -28,6 +28,7 @@ struct SwarmParams {
     int32_t *done_list, *done_count;
     const int32_t *reset_list, *reset_count;
     int E, grid, max_steps;
+    int env_base;                // MODE_STEP / MODE_OBSERVE: the launch covers envs [env_base, E) (E = end of the range)
     uint32_t flags, env_off;
     uint64_t seed;
 };
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(SWARM_TPB) void swarm_kernel(SwarmParams P) {
         }
     } else {
         if (tid < SWARM_EPB) {
-            int e = blockIdx.x * SWARM_EPB + tid;
+            int e = P.env_base + blockIdx.x * SWARM_EPB + tid;
             env_of[tid] = e < P.E ? e : -1;
         }
     }
@@ -478,6 +479,27 @@ int swarm_launch_step(grl_handle *h, const float *actions_dev, const double *act
     // auto-reset of the envs that just finished (paac/emulator_runner.py:128-132): the terminal
     // reward/done stay, the observation becomes the reset one (quirk Q6)
     return swarm_launch_reset(h, h->done_list, h->done_count, h->E);
+}
+
+// The step for envs [env_base, env_base + count) only, enqueued on the handle's CURRENT stream: the rollout of the conv policy
+// runs every chunk of envs as its own pipeline (forward -> sample -> step -> bookkeeping) on one of a few streams, so the fp64
+// VALU-bound step of one chunk overlaps the MFMA GEMMs of the others.  `slot` < 16 selects the done counter (one per stream; the
+// finished envs of the range are listed at done_list + env_base).
+int swarm_launch_step_range(grl_handle *h, const float *actions_dev, int env_base, int count, int slot) {
+    SwarmParams P = make_params(h);
+    P.actions = actions_dev;
+    P.actions64 = nullptr;
+    P.env_base = env_base;
+    P.E = env_base + count;
+    P.done_list = h->done_list + env_base;
+    P.done_count = h->done_count + slot;
+    GRL_HIP(h, hipMemsetAsync(P.done_count, 0, sizeof(int32_t), h->stream));
+    if (h->cfg.flags & GRL_F_SWARM_FAST_MATH)
+        hipLaunchKernelGGL((swarm_kernel<MODE_STEP, true>), dim3(nblocks(count)), dim3(SWARM_TPB), 0, h->stream, P);
+    else
+        hipLaunchKernelGGL((swarm_kernel<MODE_STEP, false>), dim3(nblocks(count)), dim3(SWARM_TPB), 0, h->stream, P);
+    GRL_HIP(h, hipGetLastError());
+    return swarm_launch_reset(h, P.done_list, P.done_count, count);
 }
 
 int swarm_launch_reset(grl_handle *h, const int32_t *list_dev, const int32_t *count_dev, int max_count) {
