@@ -1,6 +1,6 @@
 """Estimator objects with the reference's conf keys (fed_gym/agents/paac/policy_v_network.py,
 networks.py:100-167; conf built in scripts/train_paac_conv.py:67-83)."""
-from ... import _ffi_flat, _ffi_net
+from ... import _ffi_field, _ffi_flat, _ffi_net
 
 
 class ConvSingleAgentPolicyNetwork(object):
@@ -78,6 +78,55 @@ class FlatPolicyVNetwork(object):
     def predict(self, states, histories, session=None):
         out = self.net.predict(states, histories)
         return {'mu': out['mu'], 'sigma': out['sigma']}          # the reference's predict returns only these two (:253-264)
+
+    def get_flat_params(self):
+        return self.net.get_params()
+
+    def set_flat_params(self, flat):
+        self.net.set_params(flat)
+
+
+class ConvPolicyVFieldNetwork(object):
+    """policy_v_network.py:83-191: the field-output estimator (3x3 'same' convs + max-pools, Dense(H*W*A) mu / sigma fields
+    gathered at the agents' grid positions).  No script of the reference builds it; tests/estimators_tests.py:152-215 checks its
+    output shapes at 32x32x3, 5 filters, 2 conv layers, 3 actions.  `bind(engine)` puts it on the engine's device."""
+
+    def __init__(self, conf):
+        self.conf = conf
+        self.name = conf.get('name', 'local_learning')
+        self.num_actions = conf['num_actions']
+        self.clip_norm = conf['clip_norm']
+        self.clip_norm_type = conf['clip_norm_type']
+        self.device = conf['device']
+        self.entropy_beta = conf['entropy_regularisation_strength']
+        self.scale = conf['scale']
+        self.height, self.width, self.channels = conf['height'], conf['width'], conf['channels']
+        self.filters, self.conv_layers = conf['filters'], conf['conv_layers']
+        self.fc_hidden = 32
+        self.rnn_layers = 2
+        self.use_rnn = False          # :88 -- the history placeholder is never consumed
+        if self.clip_norm_type not in ('global', 'ignore'):
+            raise Exception('Norm type not recognized')
+        self.net = None
+
+    def _geometry(self):
+        return dict(height=self.height, width=self.width, channels=self.channels, filters=self.filters, conv_layers=self.conv_layers,
+                    num_actions=self.num_actions)
+
+    def bind(self, engine, seed=3, max_samples=256):
+        clip = self.clip_norm if self.clip_norm_type == 'global' else 0.0
+        self.net = _ffi_field.FieldNet(engine, max_samples=max_samples, scale=self.scale, entropy_beta=self.entropy_beta, clip_norm=clip,
+                                       **self._geometry())
+        self.net.set_params(_ffi_field.glorot_uniform_flat(seed, **self._geometry()))
+        return self
+
+    def predict(self, states, histories, positions, session=None):
+        """predict(states, histories, positions, session) (:175-191): histories are accepted and ignored, as in the reference."""
+        return self.net.predict(states, positions)
+
+    def train(self, states, positions, actions, advantages, critic_target, lr, apply_update=True):
+        """one session.run of a train op on the network.loss feed (states, agent_positions, actions, advantages, critic_target)"""
+        return self.net.train(states, positions, actions, advantages, critic_target, lr, apply_update)
 
     def get_flat_params(self):
         return self.net.get_params()

@@ -361,3 +361,118 @@ def numeric_grad(f, p, names, eps=1e-6, max_per=6, seed=0):
             vals.append((idx, (fp - fm) / (2 * eps)))
         out[n] = vals
     return out
+
+
+# ------------------------------------------------------------------------------------------ Field net
+# ConvPolicyVFieldNetwork (policy_v_network.py:83-191; placeholders networks.py:170-190).  PARITY UNPINNED like the two nets
+# above (the reference's only test of it is a shape test at 32x32x3, 5 filters, 2 conv layers, 3 actions:
+# tests/estimators_tests.py:152-215).  use_rnn is False in the reference (:88): the history input is never consumed.
+def field_param_shapes(height=32, width=32, channels=3, filters=5, conv_layers=2, num_actions=3, fc_hidden=32):
+    """tf.trainable_variables() creation order: the conv layers and dense1/dense2 of 'process_input', the four 'policy'
+    layers, the three 'v_s' layers."""
+    fh, fw = int(height / (2 ** conv_layers)), int(width / (2 ** conv_layers))
+    shapes, cin = [], channels
+    for i in range(conv_layers):
+        shapes += [("conv%d_w" % i, (3, 3, cin, filters)), ("conv%d_b" % i, (filters,))]
+        cin = filters
+    hwa = height * width * num_actions
+    shapes += [("dense1_w", (fh * fw * filters, 2 * fc_hidden)), ("dense1_b", (2 * fc_hidden,)),
+               ("dense2_w", (2 * fc_hidden, fc_hidden)), ("dense2_b", (fc_hidden,)),
+               ("pol1_w", (fc_hidden, 2 * fc_hidden)), ("pol1_b", (2 * fc_hidden,)),
+               ("pol2_w", (2 * fc_hidden, 2 * hwa)), ("pol2_b", (2 * hwa,)),
+               ("mu_w", (2 * hwa, hwa)), ("mu_b", (hwa,)), ("sigma_w", (2 * hwa, hwa)), ("sigma_b", (hwa,)),
+               ("v1_w", (fc_hidden, 2 * fc_hidden)), ("v1_b", (2 * fc_hidden,)), ("v2_w", (2 * fc_hidden, fc_hidden)), ("v2_b", (fc_hidden,)),
+               ("v3_w", (fc_hidden, 1)), ("v3_b", (1,))]
+    return shapes
+
+
+def _conv_same3(x, w, b):
+    """tf.layers.Conv2D(kernel_size=3, padding='same'): zero padding of one pixel on every side."""
+    xp = np.pad(x, ((0, 0), (1, 1), (1, 1), (0, 0)))
+    return _conv(xp, w, b, 1)
+
+
+def _maxpool2(a):
+    """tf.layers.MaxPooling2D(2, 2) on even H, W.  Returns pooled (N,H/2,W/2,C) and the argmax (0..3 = dy*2+dx; the FIRST maximum,
+    as the gradient of the TF op routes ties)."""
+    N, H, W, C = a.shape
+    win = a.reshape(N, H // 2, 2, W // 2, 2, C).transpose(0, 1, 3, 2, 4, 5).reshape(N, H // 2, W // 2, 4, C)
+    idx = win.argmax(axis=3)
+    return np.take_along_axis(win, idx[:, :, :, None, :], axis=3)[:, :, :, 0, :], idx
+
+
+def field_forward(p, states, positions, scale, conv_layers=2, keep=False):
+    """states (N,H,W,C), positions (N,2) int [(height_idx, width_idx)] -> mu (N,A), sigma (N,A), vs (N,)."""
+    N, H, W, _ = states.shape
+    c = {"x": [], "cols": [], "z": [], "idx": []}
+    x = states
+    for i in range(conv_layers):
+        c["x"].append(x)
+        z, cols = _conv_same3(x, p["conv%d_w" % i], p["conv%d_b" % i])
+        pooled, idx = _maxpool2(np.maximum(z, 0))
+        c["cols"].append(cols); c["z"].append(z); c["idx"].append(idx)
+        x = pooled
+    flat = x.reshape(N, -1)                                   # tf.reshape of NHWC: (h, w, f)
+    d1 = np.maximum(flat @ p["dense1_w"] + p["dense1_b"], 0)
+    d2 = np.maximum(d1 @ p["dense2_w"] + p["dense2_b"], 0)   # processed_state
+    p1 = np.maximum(d2 @ p["pol1_w"] + p["pol1_b"], 0)
+    p2 = np.maximum(p1 @ p["pol2_w"] + p["pol2_b"], 0)
+    A = p["mu_w"].shape[1] // (H * W)
+    # mus/sigmas are Dense(H*W*A) reshaped (N,H,W,A) and gathered at the agent's position (:140-152): only A columns per sample
+    col = ((positions[:, 0] * W + positions[:, 1]) * A)[:, None] + np.arange(A)[None]      # (N, A)
+    zmu = np.einsum("nk,kna->na", p2, p["mu_w"][:, col]) + p["mu_b"][col]
+    zsg = np.einsum("nk,kna->na", p2, p["sigma_w"][:, col]) + p["sigma_b"][col]
+    mu, sigma = np.tanh(zmu), _sigmoid(zsg)
+    v1 = np.maximum(d2 @ p["v1_w"] + p["v1_b"], 0)
+    v2 = np.maximum(v1 @ p["v2_w"] + p["v2_b"], 0)
+    zv = (v2 @ p["v3_w"] + p["v3_b"])[:, 0]
+    vs = -scale * softplus(zv)
+    if keep:
+        c.update(final=x, flat=flat, d1=d1, d2=d2, p1=p1, p2=p2, col=col, mu=mu, sigma=sigma, v1=v1, v2=v2, zv=zv)
+        return mu, sigma, vs, c
+    return mu, sigma, vs
+
+
+def field_loss_and_grads(p, states, positions, actions, advantages, critic_target, beta, scale, conv_layers=2):
+    """loss (policy_v_network.py:154-173: the N1 loss, entropy term included) and d loss / d params, float64."""
+    mu, sigma, vs, c = field_forward(p, states, positions, scale, conv_layers, keep=True)
+    loss, pl, cl, dmu, dsigma, dvs = gaussian_loss_terms(mu, sigma, actions, advantages, critic_target, vs, beta, scale)
+    N = states.shape[0]
+    g = {k: np.zeros_like(v) for k, v in p.items()}
+    dzmu, dzsg = dmu * (1 - mu ** 2), dsigma * sigma * (1 - sigma)
+    dp2 = np.zeros_like(c["p2"])
+    for n in range(N):            # samples in order: two agents on one pixel add into the same columns
+        cols = c["col"][n]
+        g["mu_w"][:, cols] += np.outer(c["p2"][n], dzmu[n]); g["mu_b"][cols] += dzmu[n]
+        g["sigma_w"][:, cols] += np.outer(c["p2"][n], dzsg[n]); g["sigma_b"][cols] += dzsg[n]
+        dp2[n] = p["mu_w"][:, cols] @ dzmu[n] + p["sigma_w"][:, cols] @ dzsg[n]
+    dp2 *= c["p2"] > 0
+    g["pol2_w"], g["pol2_b"] = c["p1"].T @ dp2, dp2.sum(0)
+    dp1 = (dp2 @ p["pol2_w"].T) * (c["p1"] > 0)
+    g["pol1_w"], g["pol1_b"] = c["d2"].T @ dp1, dp1.sum(0)
+    dzv = (dvs * (-scale) * _sigmoid(c["zv"]))[:, None]
+    g["v3_w"], g["v3_b"] = c["v2"].T @ dzv, dzv.sum(0)
+    dv2 = (dzv @ p["v3_w"].T) * (c["v2"] > 0)
+    g["v2_w"], g["v2_b"] = c["v1"].T @ dv2, dv2.sum(0)
+    dv1 = (dv2 @ p["v2_w"].T) * (c["v1"] > 0)
+    g["v1_w"], g["v1_b"] = c["d2"].T @ dv1, dv1.sum(0)
+    dd2 = (dp1 @ p["pol1_w"].T + dv1 @ p["v1_w"].T) * (c["d2"] > 0)
+    g["dense2_w"], g["dense2_b"] = c["d1"].T @ dd2, dd2.sum(0)
+    dd1 = (dd2 @ p["dense2_w"].T) * (c["d1"] > 0)
+    g["dense1_w"], g["dense1_b"] = c["flat"].T @ dd1, dd1.sum(0)
+    dx = (dd1 @ p["dense1_w"].T).reshape(c["final"].shape)
+    for i in reversed(range(conv_layers)):
+        z, idx = c["z"][i], c["idx"][i]
+        Nn, Hh, Ww, F = z.shape
+        # max-pool gradient to the argmax of each window, then ReLU
+        dwin = np.zeros((Nn, Hh // 2, Ww // 2, 4, F))
+        np.put_along_axis(dwin, idx[:, :, :, None, :], dx[:, :, :, None, :], axis=3)
+        da = dwin.reshape(Nn, Hh // 2, Ww // 2, 2, 2, F).transpose(0, 1, 3, 2, 4, 5).reshape(Nn, Hh, Ww, F)
+        dz = da * (z > 0)
+        w = p["conv%d_w" % i]
+        g["conv%d_w" % i] = (c["cols"][i].reshape(-1, c["cols"][i].shape[-1]).T @ dz.reshape(-1, F)).reshape(w.shape)
+        g["conv%d_b" % i] = dz.sum(axis=(0, 1, 2))
+        xs = c["x"][i].shape
+        dxp = _col2im(dz @ w.reshape(-1, F).T, (xs[0], xs[1] + 2, xs[2] + 2, xs[3]), 3, 3, 1)
+        dx = dxp[:, 1:-1, 1:-1, :]
+    return loss, pl, cl, g, (mu, sigma, vs)

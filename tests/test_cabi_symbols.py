@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _declared():
     names = set()
-    for h in ("goldsrl.h", "goldsrl_net.h", "goldsrl_flatnet.h"):
+    for h in ("goldsrl.h", "goldsrl_net.h", "goldsrl_flatnet.h", "goldsrl_fieldnet.h"):
         text = open(os.path.join(ROOT, "include", h)).read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
         names |= set(re.findall(r"\b(grl_[a-z0-9_]+)\s*\(", text))
@@ -19,13 +19,13 @@ def _declared():
 
 
 def test_every_declared_symbol_is_exported():
-    from goldsrl import _ffi, _ffi_flat, _ffi_net
-    lib = _ffi.load_library(extra_signatures=dict(_ffi_net.NET_SIGNATURES, **_ffi_flat.FNET_SIGNATURES))
+    from goldsrl import _ffi, _ffi_field, _ffi_flat, _ffi_net
+    lib = _ffi.load_library(extra_signatures=dict(_ffi_net.NET_SIGNATURES, **dict(_ffi_flat.FNET_SIGNATURES, **_ffi_field.FIELD_SIGNATURES)))
     declared = _declared()
     assert len(declared) >= 50
     for name in declared:
         assert hasattr(lib, name), "include/*.h declares %s but libgoldsrl.so does not export it" % name
-    bound = set(_ffi.SIGNATURES) | set(_ffi_net.NET_SIGNATURES) | set(_ffi_flat.FNET_SIGNATURES)
+    bound = set(_ffi.SIGNATURES) | set(_ffi_net.NET_SIGNATURES) | set(_ffi_flat.FNET_SIGNATURES) | set(_ffi_field.FIELD_SIGNATURES)
     assert bound == set(declared), (sorted(bound - set(declared)), sorted(set(declared) - bound))
     assert lib.grl_abi_version() == 1
 

@@ -116,3 +116,47 @@ def test_flat_net_matches_torch_autograd(dims):
     for name, _ in NN.flat_param_shapes(**dims):
         ref = tp[name].grad.numpy()
         np.testing.assert_allclose(g[name], ref, rtol=1e-8, atol=1e-10 * (np.abs(ref).max() + 1e-30), err_msg=name)
+
+
+def test_field_net_matches_torch_autograd():
+    """ConvPolicyVFieldNetwork (policy_v_network.py:83-191): 3x3 'same' convs + 2x2 max-pools, dense stack, Dense(H*W*A) heads
+    gathered at the agent's position -- the numpy restatement's forward and every gradient against torch autograd, at the
+    reference test's geometry (tests/estimators_tests.py:152-176) incl. two agents on the same pixel."""
+    H = W = 32
+    C, F, L, A, N = 3, 5, 2, 3, 6
+    shapes = NN.field_param_shapes(H, W, C, F, L, A)
+    rng = np.random.RandomState(1)
+    p = {n: rng.normal(size=s) * (0.3 / np.sqrt(s[0] if len(s) == 2 else 27) if n.endswith("_w") else 0.05) for n, s in shapes}
+    states = rng.uniform(size=(N, H, W, C))
+    positions = np.stack([rng.randint(0, H, N), rng.randint(0, W, N)], axis=1)
+    positions[3] = positions[1]                      # shared output pixel: gradients of both samples add
+    actions, adv, y = rng.uniform(size=(N, A)), rng.normal(size=N), rng.normal(size=N)
+    beta, scale = 0.02, 10.0
+    loss, pl, cl, g, (mu, sigma, vs) = NN.field_loss_and_grads(p, states, positions, actions, adv, y, beta, scale, L)
+    assert mu.shape == (N, A) and sigma.shape == (N, A) and vs.shape == (N,)
+
+    tp = _t(p)
+    x = torch.tensor(states)
+    for i in range(L):
+        z = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), tp["conv%d_w" % i].permute(3, 2, 0, 1), bias=tp["conv%d_b" % i], padding=1)
+        x = torch.nn.functional.max_pool2d(torch.relu(z), 2).permute(0, 2, 3, 1)
+    flat = x.reshape(N, -1)
+    d1 = torch.relu(flat @ tp["dense1_w"] + tp["dense1_b"])
+    d2 = torch.relu(d1 @ tp["dense2_w"] + tp["dense2_b"])
+    p1 = torch.relu(d2 @ tp["pol1_w"] + tp["pol1_b"])
+    p2 = torch.relu(p1 @ tp["pol2_w"] + tp["pol2_b"])
+    mus = torch.tanh(p2 @ tp["mu_w"] + tp["mu_b"]).reshape(N, H, W, A)             # the full field, as the reference builds it
+    sgs = torch.sigmoid(p2 @ tp["sigma_w"] + tp["sigma_b"]).reshape(N, H, W, A)
+    idx = torch.arange(N)
+    tmu, tsg = mus[idx, torch.tensor(positions[:, 0]), torch.tensor(positions[:, 1])], sgs[idx, torch.tensor(positions[:, 0]), torch.tensor(positions[:, 1])]
+    v1 = torch.relu(d2 @ tp["v1_w"] + tp["v1_b"])
+    v2 = torch.relu(v1 @ tp["v2_w"] + tp["v2_b"])
+    tvs = -scale * torch.nn.functional.softplus((v2 @ tp["v3_w"] + tp["v3_b"])[:, 0])
+    tl, tpl, tcl = _gauss_loss(tmu, tsg, torch.tensor(actions), torch.tensor(adv), torch.tensor(y), tvs, beta, scale, True)
+    tl.backward()
+    np.testing.assert_allclose(mu, tmu.detach().numpy(), rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(sigma, tsg.detach().numpy(), rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(vs, tvs.detach().numpy(), rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose([loss, pl, cl], [tl.item(), tpl.item(), tcl.item()], rtol=1e-10)
+    for name, _ in shapes:
+        np.testing.assert_allclose(g[name], tp[name].grad.numpy(), rtol=1e-8, atol=1e-11, err_msg=name)
