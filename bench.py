@@ -46,7 +46,7 @@ MFMA_BF16_PEAK_TFLOPS = 2516.6       # MI355X_MICROARCH.md: dense bf16 matrix pe
 # (net_gemm.h), so the matrix pipe bounds the fp32-equivalent rate at 2516.6 / 6
 BF16_PRODUCTS_PER_FP32 = 6
 MFMA_X6_PEAK_TFLOPS = MFMA_BF16_PEAK_TFLOPS / BF16_PRODUCTS_PER_FP32
-GEMM_TRAFFIC_FILE = "r01_gemm_traffic.json"   # PMC pass of the GEMM kernels (tools/run_prof.sh); refreshed per round
+GEMM_TRAFFIC_FILE = "r02_gemm_traffic.json"   # PMC pass of the GEMM kernels (tools/run_prof.sh); refreshed per round
 
 
 def parse():
