@@ -91,6 +91,10 @@ struct NetLane {
     float *slabb;              // per-wave-tile column sums written by the EpiGradSum / EpiGradStride2 data-gradient GEMMs (bias gradients)
     float *slab1b;             // per-workgroup sums of agent_ds_kernel's dS corrections (conv1's bias gradient)
     float *cfold;              // kFoldParts x 32 partial sums of fold_class_sums_kernel
+    // conv2 corrections as a GEMM (net_shared.inc): A rows, class sort, canonical-slot maps
+    float *carow;
+    int *cperm, *cblkcnt, *cblkoff, *cgoff, *cslot;
+    signed char *ctilegroup;
     double *slab64;
     float *ro_mu;              // chunk-sized scratch of the gradient step (cmu csigma cvs dzh cact cadv cy)
     float *ws_a3, *ws_d1, *ws_d2, *ws_p1, *ws_v1, *ws_v2, *ws_a3sh, *ws_d3;   // chunk workspace (the default binding)
@@ -112,6 +116,8 @@ struct grl_net : NetLane {
     float *w3t, *w2t;          // rearranged conv weights for the data gradients
     float *w3f;                // w3f[(tap,co)][ci] = W3[tap][ci][co] (slot product GEMM of conv3's forward)
     int shared_trunk;
+    int expand2_gemm, ctiles;  // conv2's per-agent corrections as a class-sorted GEMM (default) or the LDS-resident kernel (GRL_NET_EXPAND2=lds)
+    float *w2corr;             // [4 classes][576][128] kernel slices of that GEMM, rebuilt with the transposes
     grl::HeadOff ho;           // offsets of the head / value parameters for this net's num_actions
     int npad, ptiles, pslices;
     size_t slab_floats;
@@ -246,6 +252,7 @@ __global__ void transpose_kernel(const float *__restrict__ src, int K, int N, fl
         if (n0 + r < N && k0 + (int)threadIdx.x < K) dst[(long)(n0 + r) * K + k0 + threadIdx.x] = tile[threadIdx.x][r];
 }
 
+__global__ void conv2_corr_weights_kernel(const float *__restrict__ w2, float *__restrict__ bt);      // net_shared.inc
 // keep paramsT in step with params (after set_params, Adam, broadcast)
 static void refresh_transposes(grl_net *net) {
     const struct { long off; int K, N; } L[] = {
@@ -254,6 +261,8 @@ static void refresh_transposes(grl_net *net) {
     for (const auto &l : L)
         hipLaunchKernelGGL(transpose_kernel, dim3((l.N + 31) / 32, (l.K + 31) / 32), dim3(32, 8), 0, net->h->stream, net->params + l.off,
                            l.K, l.N, net->paramsT + l.off);
+    hipLaunchKernelGGL(conv2_corr_weights_kernel, dim3((4 * 576 * 128 + 255) / 256), dim3(256), 0, net->h->stream, net->params + ConvOffsets::c2w,
+                       net->w2corr);
     for (int tap = 0; tap < 9; ++tap)     // w3f[(tap, co)][ci]: each tap's 64x64 block transposed
         hipLaunchKernelGGL(transpose_kernel, dim3(2, 2), dim3(32, 8), 0, net->h->stream, net->params + ConvOffsets::c3w + tap * 4096, 64, 64,
                            net->w3f + tap * 4096);
@@ -595,6 +604,13 @@ static int alloc_lane_forward(grl_net *n) {
     if (rc == GRL_OK) rc = nalloc(n, &n->rowagent, c * 9);
     if (rc == GRL_OK) rc = nalloc(n, &n->rowdesc, c * 9);
     if (rc == GRL_OK) rc = nalloc(n, &n->sblk, 1024);
+    A(&n->carow, c * 128);
+    if (rc == GRL_OK) rc = nalloc(n, &n->cperm, (size_t)n->ctiles * 256);
+    if (rc == GRL_OK) rc = nalloc(n, &n->cblkcnt, ((c + 255) / 256) * 4);
+    if (rc == GRL_OK) rc = nalloc(n, &n->cblkoff, ((c + 255) / 256) * 4);
+    if (rc == GRL_OK) rc = nalloc(n, &n->cgoff, 8);
+    if (rc == GRL_OK) rc = nalloc(n, &n->cslot, c * 9);
+    if (rc == GRL_OK) rc = nalloc(n, &n->ctilegroup, (size_t)n->ctiles);
     return rc;
 }
 
@@ -659,12 +675,17 @@ int grl_net_create(grl_handle *h, const grl_net_config *cfg, grl_net **out) {
     n->lane_stream[0] = h->stream; n->ev_fork = nullptr; n->nlanes = 1;
     const size_t c = n->chunk;
     n->ptiles = (int)((c + 255) / 256) + 9;
+    n->ctiles = (int)((c + 255) / 256) + 4;
+    {   // A/B switch of the conv2 corrections (default: GEMM)
+        const char *e2 = getenv("GRL_NET_EXPAND2");
+        n->expand2_gemm = (e2 && strcmp(e2, "lds") == 0) ? 0 : 1;
+    }
     n->pslices = (int)((c + 1023) / 1024) + 9;
     n->npad = (int)((c + 255) / 256 * 256);
     int rc = GRL_OK;
     auto A = [&](float **p, size_t cnt) { if (rc == GRL_OK) rc = nalloc(n, p, cnt); };
     A(&n->params, n->ho.total); A(&n->paramsT, n->ho.total); A(&n->adam_m, n->ho.total); A(&n->adam_v, n->ho.total);
-    A(&n->w3f, 576 * 64); A(&n->stats, 16);
+    A(&n->w3f, 576 * 64); A(&n->stats, 16); A(&n->w2corr, 4 * 576 * 128);
     int nlanes = (cfg->reserved & GRL_NET_F_SINGLE_STREAM) ? 1 : 4;      // measured at 32 768 envs: 1.41 / 1.22 / 1.16 / 1.13 / 1.14 s per update with 1 / 2 / 3 / 4 / 8
     if (const char *env = getenv("GRL_NET_LANES")) { int v = atoi(env); if (v >= 1 && v <= GRL_MAX_LANES) nlanes = v; }      // tuning knob
     for (int k = 0; k < nlanes && rc == GRL_OK; ++k) {       // lane k's forward workspace (allocated into *n, then parked)

@@ -26,7 +26,15 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace grl {
+
+// an epilogue may ask for the sign bits of what it stores, one 64-bit word per output row and 64-column block (kRowBits)
+template <class E, class = void>
+struct epi_row_bits : std::false_type {};
+template <class E>
+struct epi_row_bits<E, std::void_t<decltype(E::kRowBits)>> : std::bool_constant<E::kRowBits> {};
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -310,6 +318,33 @@ struct PatchRows {
     }
 };
 
+// conv2's per-agent corrections as ONE GEMM (net_shared.inc, forward): row = agent (sorted by the parity class of its conv1 window,
+// perm[slot] = sample or -1, tilegroup[slot >> 8] = class or -1), K = 4 conv1 candidates x 32 channels of (a1_a - a1_sh), N = 9
+// canonical conv2 outputs x 64 channels against the class's own 576-row block of Bt.
+struct CorrRows {
+    static constexpr bool kRelu = false;
+    const float *base;
+    const int *perm;
+    const signed char *tilegroup;
+    int rows;
+    __device__ __forceinline__ int K() const { return 128; }
+    __device__ __forceinline__ void row(int r, long &off, int &iy0, int &ix0) const {
+        const int m = perm[r];
+        iy0 = m < 0 ? -1 : 0;
+        ix0 = 0;
+        off = (long)(m < 0 ? 0 : m) * 128;
+    }
+    __device__ __forceinline__ void tap(int k0, int &toff, int &ty, int &tx) const {
+        toff = k0;
+        ty = tx = 0;
+    }
+    __device__ __forceinline__ bool ok(int iy0, int, int, int) const { return iy0 >= 0; }
+    __device__ __forceinline__ bool tile_ok(int, int) const { return true; }
+    __device__ __forceinline__ bool tile_active(int m0) const { return tilegroup[m0 >> 8] >= 0; }
+    __device__ __forceinline__ int bk(int k0, int) const { return k0; }
+    __device__ __forceinline__ int bn(int n0, int m0) const { return n0 + tilegroup[m0 >> 8] * 576; }
+};
+
 // ---------------------------------------------------------------------------- epilogues
 // An epilogue is evaluated in two passes so that every load it needs is in flight before the first store is issued
 // (stores and loads through unrelated pointers cannot be reordered by the compiler: one load -> select -> store chain per
@@ -334,6 +369,44 @@ struct EpiBiasAct {
         v += ea;
         if (act == ACT_RELU) v = fmaxf(v, 0.f);
         C[(long)r * ldc + c] = v;
+    }
+};
+
+struct EpiBiasDual {
+    static constexpr bool kColSum = false;   // C[r][c] = v + bias[c] and C2[r][c] = relu(v + bias[c]): pre-activation and activation in one pass
+    float *C, *C2;
+    int ldc;
+    const float *bias;
+    __device__ __forceinline__ int row_aux(int) const { return 0; }
+    __device__ __forceinline__ float elem_aux(int, int c, int) const { return bias[c]; }
+    __device__ __forceinline__ void store(int r, int c, float v, int, float ea) const {
+        v += ea;
+        C[(long)r * ldc + c] = v;
+        C2[(long)r * ldc + c] = fmaxf(v, 0.f);
+    }
+};
+
+// conv2 corrections (CorrRows): column block j = c >> 6 is the agent's canonical conv2 output j; cslot[m*9+j] = its compact slot
+// row (or -1).  On entry d2[slot] holds the env's shared PRE-activation of that pixel (conv2_prep_kernel copies it there); on exit
+// a2_a - a2sh = relu(z + v) - relu(z), plus one word of 64 channel sign bits of relu(z + v) per slot row.  The slot index is
+// resolved once per output row (row_aux_n: the workgroup's 64 columns are one canonical output), not per element.
+struct EpiConv2Corr {
+    static constexpr bool kColSum = false;
+    static constexpr bool kRowBits = true;
+    float *d2;
+    unsigned long long *m2;
+    const int *perm, *cslot;
+    __device__ __forceinline__ int row_aux_n(int r, int colbase) const {
+        const int m = perm[r];
+        return m < 0 ? -1 : cslot[m * 9 + (colbase >> 6)];
+    }
+    __device__ __forceinline__ float elem_aux(int, int c, int slot) const { return slot >= 0 ? d2[(long)slot * 64 + (c & 63)] : 0.f; }
+    __device__ __forceinline__ void store(int, int c, float v, int slot, float z) const {
+        if (slot >= 0) d2[(long)slot * 64 + (c & 63)] = fmaxf(v + z, 0.f) - fmaxf(z, 0.f);
+    }
+    __device__ __forceinline__ bool bit(float v, float z) const { return v + z > 0.f; }
+    __device__ __forceinline__ void store_bits(int, int, unsigned long long w, int slot) const {
+        if (slot >= 0) m2[slot] = w;
     }
 };
 
@@ -657,7 +730,10 @@ __global__ __launch_bounds__(256, 2) void gemm_rowk(AG ag, const float *__restri
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) rax[a][r] = epi.row_aux(min(erow + a * 16 + r, M - 1));
+        for (int r = 0; r < 4; ++r) {
+            if constexpr (epi_row_bits<Epi>::value) rax[a][r] = epi.row_aux_n(min(erow + a * 16 + r, M - 1), n0 + wn * WN);
+            else rax[a][r] = epi.row_aux(min(erow + a * 16 + r, M - 1));
+        }
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -688,6 +764,23 @@ __global__ __launch_bounds__(256, 2) void gemm_rowk(AG ag, const float *__restri
             const int col = ecol + b * 16;
             if (kg == 0 && col < N) epi.csum[(long)(by * WGM + wm) * N + col] = sum;
         }
+    }
+    if constexpr (epi_row_bits<Epi>::value) {      // sign bits of the stored values: one word per row and 64-column block of this wave
+        static_assert(WN == 64, "a wave covers exactly one 64-column block");
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                unsigned long long w = 0ull;
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    // lane (kg, l16) holds row 4*kg + r, column 16*b + l16: bits [16 kg, 16 kg + 16) of the ballot are this row's
+                    const unsigned long long bal = __ballot(epi.bit(acc[a][b][r], eax[a][b][r]));
+                    w |= ((bal >> (16 * kg)) & 0xFFFFull) << (16 * b);
+                }
+                const int row = erow + a * 16 + r;
+                if (l16 == 0 && row < M) epi.store_bits(row, n0 + wn * WN, w, rax[a][r]);
+            }
     }
 #undef GRL_LOAD_TILE
 #undef GRL_STORE_TILE

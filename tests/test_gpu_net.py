@@ -265,8 +265,12 @@ def test_gradient_paths_agree_at_tile_multiple_sizes():
             # dense1's pre-activation is rounded differently by the two evaluations (per-env part + patch part against one
             # 3136-long sum): of the 1.3 million ReLU inputs a handful sit within that round-off of zero and get the other
             # mask, each moving the gradients of dense1 and of everything below it by one sample-unit's worth (observed
-            # 3e-5 in dense1, up to 3e-4 in conv1_w, where the sum cancels most); layers above dense1 see no masks flip
-            tol = 1e-3 if name.startswith(("conv", "dense1")) else 5e-6
+            # 3e-5 in dense1, up to 3e-4 in conv1_w, where the sum cancels most); layers above dense1 see no masks flip.
+            # Round 2: conv2's per-agent corrections come out of an MFMA GEMM instead of an FMA chain (1.5e-8 apart, no sign
+            # differs: tools/cmp_expand2.py); on this seed that moves a few more near-zero ReLU inputs of conv3 / dense1 across
+            # zero -- 1.1e-4 in dense1 (3 elements), 1.45e-3 in conv1_w (tools/diag_paths.py prints both kernels side by side).
+            # The statistic is "which handful of inputs sits within round-off of zero", so the bound is loose by nature.
+            tol = 3e-3 if name == "conv1_w" else (1e-3 if name.startswith(("conv", "dense1")) else 5e-6)
             assert err < tol, (name, err)
     for s in stats[:4]:
         np.testing.assert_allclose(s["loss"], stats[4]["loss"], rtol=1e-5)
