@@ -115,6 +115,32 @@ def test_bench_gpus_2_without_a_launcher_reports_two_ranks():
     assert j["roofline"]["frac"] > 0
 
 
+@pytest.mark.timeout(900)
+def test_grid_learner_sharded_over_two_ranks(tmp_path):
+    """The learner itself on two ranks (GridPAACLearner.train: engine with env_id_offset = rank * E, gradient exchange, R6 with
+    the rank's offset in the reference's global_step): episode log and parameters equal the single-process run on 2E envs."""
+    from goldsrl import distributed as D
+    import _learner_rank as L
+    E, T, U = 16, 20, 2
+    rc = D.spawn_local_ranks([sys.executable, os.path.join(ROOT, "tests", "_learner_rank.py"), str(E), str(T), str(U), str(tmp_path)], 2)
+    assert rc == 0
+    r0, r1 = np.load(tmp_path / "learner_rank0.npz"), np.load(tmp_path / "learner_rank1.npz")
+    assert str(r0["exchange"]) == "gloo-host-fallback" and int(r0["global_step"]) == int(r1["global_step"]) == U * 2 * E * T
+    assert np.array_equal(r0["params"], r1["params"])
+    single = tmp_path / "single"
+    single.mkdir()
+    L.run(2 * E, T, U, str(single), 1)
+    s = np.load(single / "learner_rank0.npz")
+    assert int(s["global_step"]) == U * 2 * E * T
+    # R6 across ranks: the union of the two logs is the single-process log (global_step of the summary, global env id, length, total)
+    both = np.concatenate([r0["log"], r1["log"]])
+    both = both[np.lexsort((both[:, 1], both[:, 0]))]
+    assert both.shape == s["log"].shape and len(both) == 5 * 2 * E          # TimeLimit 8: episodes end at steps 8..40
+    assert np.array_equal(both[:, :3], s["log"][:, :3])
+    np.testing.assert_allclose(both[:, 3], s["log"][:, 3], rtol=1e-6)       # from the 2nd update on the policies differ by round-off
+    assert np.abs(r0["params"] - s["params"]).max() <= 0.05 * 1e-4 * U
+
+
 def test_flat_net_rccl_communicator_world_size_1():
     # the RCCL calls themselves (init, broadcast, all-reduce inside train_rollout) with the one rank a one-GPU box allows
     import _shard_rank as W
