@@ -200,3 +200,20 @@ def test_philox_known_answer():
     assert (u0 >= 0).all() and (u0 < 1).all() and abs(u0.mean() - 0.5) < 0.05
     n0, n1 = O.normal_pair(O.rng_block(1692, np.arange(20000), 0, 1, 3))
     assert abs(n0.mean()) < 0.03 and abs(n1.std() - 1) < 0.03
+
+
+def test_episode_bookkeeping_restatement_on_a_hand_example():
+    # paac.py:142-157 / 331-349 by hand: 2 envs, 3 steps; env 1 finishes at step 1 (0-based), env 0 at step 2
+    rew = np.array([[1.0, 10.0], [2.0, 20.0], [4.0, 40.0]], np.float32)
+    done = np.array([[0, 0], [0, 1], [1, 0]], np.uint8)
+    recs, total, steps, gs = O.episode_bookkeeping(rew, done, global_step=100)
+    # global_step += 1 per env inside a step, in env order: (t=1, e=1) is the 4th increment, (t=2, e=0) the 5th
+    assert recs == [(104, 1, 2, 30.0), (105, 0, 3, 7.0)]
+    assert total.tolist() == [0.0, 40.0] and steps.tolist() == [0, 1] and gs == 106
+    # carried over into the next rollout
+    recs2, total2, steps2, gs2 = O.episode_bookkeeping(rew[:1], np.array([[0, 1]], np.uint8), total, steps, gs)
+    assert recs2 == [(108, 1, 2, 50.0)] and total2.tolist() == [1.0, 0.0] and gs2 == 108
+    # float64 accumulation of the float32 rewards (numpy 1.13: `0 + np.float32` is float64)
+    r = np.full((3, 1), np.float32(0.1))
+    recs3, *_ = O.episode_bookkeeping(r, np.array([[0], [0], [1]], np.uint8))
+    assert recs3[0][3] == float(np.float32(0.1)) * 3 or abs(recs3[0][3] - 3 * float(np.float32(0.1))) < 1e-15
