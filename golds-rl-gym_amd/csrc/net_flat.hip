@@ -9,6 +9,7 @@
 // [feature][sample] (row stride 65) and every dense layer and every gradient is a small fp32 MFMA GEMM against
 // those rows (net_flat_mfma.inc).  Weight gradients are summed per workgroup into private slabs and reduced in
 // a fixed order (bitwise reproducible).
+#include <stdlib.h>
 #include <string.h>
 
 #include <cmath>
@@ -213,7 +214,13 @@ static FlatArgs base_args(grl_fnet *net, int n, const float *states, const float
 static int launch_forward(grl_fnet *net, int n, const float *states, const float *hist, float *mu, float *sigma, float *vs, bool save,
                           const int32_t *nhist = nullptr) {
     FlatArgs a = base_args(net, n, states, hist, mu, sigma, vs, save, nhist);
-    hipLaunchKernelGGL(flat_forward_kernel, dim3((n + 63) / 64), dim3(256), FLAT_LDS_BYTES, net->h->stream, a);
+    const int groups = (n + 63) / 64;
+    const size_t wbytes = (size_t)(net->cfg.temporal_size + FH) * 3 * FH * sizeof(float);
+    static const int wlds_max_groups = getenv("GRL_FLAT_WLDS_GROUPS") ? atoi(getenv("GRL_FLAT_WLDS_GROUPS")) : 512;      // tuning knob
+    if (groups <= wlds_max_groups)
+        hipLaunchKernelGGL(flat_forward_kernel<true>, dim3(groups), dim3(256), FLAT_LDS_BYTES + wbytes, net->h->stream, a, (int)FLAT_LDS_ROWS);
+    else
+        hipLaunchKernelGGL(flat_forward_kernel<false>, dim3(groups), dim3(256), FLAT_LDS_BYTES, net->h->stream, a, (int)FLAT_LDS_ROWS);
     FNET_HIP(net, hipGetLastError());
     return GRL_OK;
 }
@@ -370,7 +377,10 @@ int grl_fnet_create(grl_handle *h, const grl_fnet_config *cfg, grl_fnet **out) {
     n->ro_graph = nullptr; n->ro_graph_T = 0; n->ro_graph_ep = false;
     n->last_n = 0; n->comm = nullptr; n->comm_world = 1; n->comm_rank = 0;
     hipError_t e = hipSuccess;
-    if (rc == GRL_OK) e = hipFuncSetAttribute((const void *)flat_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLAT_LDS_BYTES);
+    if (rc == GRL_OK) e = hipFuncSetAttribute((const void *)flat_forward_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLAT_LDS_BYTES);
+    if (rc == GRL_OK && e == hipSuccess)
+        e = hipFuncSetAttribute((const void *)flat_forward_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(FLAT_LDS_BYTES + (size_t)(MAXD + FH) * 3 * FH * sizeof(float)));
     if (rc == GRL_OK && e == hipSuccess)
         e = hipFuncSetAttribute((const void *)flat_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLAT_LDS_BYTES);
     if (rc == GRL_OK && e != hipSuccess) rc = ffail(n, GRL_E_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
