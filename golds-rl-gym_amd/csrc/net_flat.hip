@@ -216,7 +216,7 @@ static int launch_forward(grl_fnet *net, int n, const float *states, const float
     FlatArgs a = base_args(net, n, states, hist, mu, sigma, vs, save, nhist);
     const int groups = (n + 63) / 64;
     const size_t wbytes = (size_t)(net->cfg.temporal_size + FH) * 3 * FH * sizeof(float);
-    static const int wlds_max_groups = getenv("GRL_FLAT_WLDS_GROUPS") ? atoi(getenv("GRL_FLAT_WLDS_GROUPS")) : 512;      // tuning knob
+    static const int wlds_max_groups = getenv("GRL_FLAT_WLDS_GROUPS") ? atoi(getenv("GRL_FLAT_WLDS_GROUPS")) : 256;      // one workgroup per CU; measured (tools/bench_trade_sizes.py): 128 / 256 groups 7.6 -> 5.5 ms, 384 / 512 groups 8.5 -> 10.4 ms
     if (groups <= wlds_max_groups)
         hipLaunchKernelGGL(flat_forward_kernel<true>, dim3(groups), dim3(256), FLAT_LDS_BYTES + wbytes, net->h->stream, a, (int)FLAT_LDS_ROWS);
     else
