@@ -116,6 +116,29 @@ def test_bench_gpus_2_without_a_launcher_reports_two_ranks():
 
 
 @pytest.mark.timeout(900)
+def test_flat_learner_sharded_over_two_ranks(tmp_path):
+    """PAACLearner (Solow, FlatPolicyVNetwork) on two ranks: same wiring as the grid learner, flat net's exchange."""
+    from goldsrl import distributed as D
+    import _learner_rank as L
+    E, T, U = 64, 20, 2
+    rc = D.spawn_local_ranks([sys.executable, os.path.join(ROOT, "tests", "_learner_rank.py"), str(E), str(T), str(U), str(tmp_path), "flat"], 2)
+    assert rc == 0
+    r0, r1 = np.load(tmp_path / "learner_rank0.npz"), np.load(tmp_path / "learner_rank1.npz")
+    assert str(r0["exchange"]) == "gloo-host-fallback" and int(r0["global_step"]) == U * 2 * E * T
+    assert np.array_equal(r0["params"], r1["params"])
+    single = tmp_path / "single"
+    single.mkdir()
+    L.run(2 * E, T, U, str(single), 1, "flat")
+    s = np.load(single / "learner_rank0.npz")
+    both = np.concatenate([r0["log"], r1["log"]])
+    both = both[np.lexsort((both[:, 1], both[:, 0]))]
+    assert both.shape == s["log"].shape and len(both) >= 2 * E
+    assert np.array_equal(both[:, :3], s["log"][:, :3])
+    np.testing.assert_allclose(both[:, 3], s["log"][:, 3], rtol=1e-4)
+    assert np.abs(r0["params"] - s["params"]).max() <= 0.05 * 1e-4 * U
+
+
+@pytest.mark.timeout(900)
 def test_grid_learner_sharded_over_two_ranks(tmp_path):
     """The learner itself on two ranks (GridPAACLearner.train: engine with env_id_offset = rank * E, gradient exchange, R6 with
     the rank's offset in the reference's global_step): episode log and parameters equal the single-process run on 2E envs."""
