@@ -60,6 +60,7 @@ using GatherT2 = ConvGather<10, 10, 1, 1, -1, -1, 2, 2, 64, 9, 9, true>;      //
 // of one chunk overlap the MFMA GEMMs of the others; grl_net derives from it, so kernels keep using net->d1 etc. and
 // use_lane() swaps the whole pointer set between chunk enqueues (host-side, sequential).
 constexpr int GRL_MAX_LANES = 8;
+constexpr int kLossScaleAt = 8, kLossBoundAt = 10;      // slots of grl_net::stats (net_train.inc: loss scale)
 struct NetLane {
     float *grads;              // this lane's gradient accumulator (lane 0's is THE gradient; lane 1's is added before the all-reduce)
     // forward activations (chunk)
@@ -116,16 +117,17 @@ struct grl_net : NetLane {
     float *w3t, *w2t;          // rearranged conv weights for the data gradients
     float *w3f;                // w3f[(tap,co)][ci] = W3[tap][ci][co] (slot product GEMM of conv3's forward)
     int shared_trunk;
+    int loss_scale_on;         // per-pass power-of-two scale of the head gradients (net_train.inc); GRL_NET_LOSS_SCALE=off disables it
     int expand2_gemm, ctiles;  // conv2's per-agent corrections as a class-sorted GEMM (default) or the LDS-resident kernel (GRL_NET_EXPAND2=lds)
     float *w2corr;             // [4 classes][576][128] kernel slices of that GEMM, rebuilt with the transposes
     grl::HeadOff ho;           // offsets of the head / value parameters for this net's num_actions
     int npad, ptiles, pslices, pslice_rows, pwgrad_xcd;      // dense1 patch weight gradient: slice length and tile order (tuning knobs)
     size_t slab_floats;
-    float *stats;              // device: loss sums
+    float *stats;              // device: [0..4] loss parts / norm / clip factor, [8..9] loss scale S and 1/S, [10] bits of the head-gradient bound
     // rollout storage (allocated by grl_net_rollout)
     int T, B;
     uint8_t *ro_lb, *ro_ab, *ro_pos, *ro_done;      // ro_done (T,E): episode_over after each step (R6 / tests; the grid return ignores it, Q5)
-    float *ro_act, *ro_envact, *ro_val, *ro_rew, *ro_y, *ro_adv, *ro_boot, *ro_sigma;
+    float *ro_act, *ro_envact, *ro_val, *ro_rew, *ro_y, *ro_adv, *ro_boot, *ro_pmu, *ro_psg;
     float *mu, *sigma, *vs;    // (B,2) (B,2) (B) of the last predict
     uint8_t *tmp_lb, *tmp_ab, *tmp_pos;
     int tmp_envs;
@@ -677,6 +679,8 @@ int grl_net_create(grl_handle *h, const grl_net_config *cfg, grl_net **out) {
     n->ptiles = (int)((c + 255) / 256) + 9;
     n->ctiles = (int)((c + 255) / 256) + 4;
     {   // A/B switch of the conv2 corrections (default: GEMM)
+        const char *lsk = getenv("GRL_NET_LOSS_SCALE");      // "off": S = 1, to show what the scale is for (tests)
+        n->loss_scale_on = (lsk && strcmp(lsk, "off") == 0) ? 0 : 1;
         const char *e2 = getenv("GRL_NET_EXPAND2");
         n->expand2_gemm = (e2 && strcmp(e2, "lds") == 0) ? 0 : 1;
     }

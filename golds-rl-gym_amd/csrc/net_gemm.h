@@ -9,18 +9,27 @@
 //        data gradient: Bt = W itself (dX = dY * W^T), or a rearranged kernel for the transposed convs
 //   gemm_tn<BM,BN,WGM,WGN>     C[I,J] = sum_m A[m,I] * B[m,J]   (weight gradient, split over m into slabs)
 //
-// Arithmetic.  The reference computes in float32, and so do these kernels -- but on the bf16 matrix pipe, which on
+// Arithmetic.  The reference computes in float32, and so do these kernels -- but on the fp16 matrix pipe, which on
 // CDNA4 runs 16x the rate of v_mfma_f32_32x32x2_f32 (2.5 PFLOP/s against 157 TFLOP/s).  While a tile is staged into
-// LDS every fp32 operand x is split EXACTLY into three bf16 numbers x = h + m + l (8 + 8 + 8 significand bits by
-// truncation: h = upper half of x, m = upper half of x - h, l = x - h - m; nothing is rounded away).  A product
-// a * b is then nine bf16 x bf16 terms, each exact in fp32; the six of weight >= 2^-24 |a||b| (hh, hm, mh, mm, hl, lh)
-// are accumulated in fp32 by v_mfma_f32_16x16x32_bf16, the three of weight <= 2^-24 (ml, lm, ll: below one fp32 ulp of
-// the product) are dropped.  Six bf16 MFMAs per K = 16 step replace eight fp32 ones: 2.7x the matrix-pipe rate, and the
-// error against a double-precision reference is the same as the fp32 MFMA loop's (tools/ubench/gemm_x6.hip: rms error
-// relative to sum|a||b| 2.0-2.1e-8 against 2.4e-8 on the dense1 / dense2 / head shapes).
+// LDS every fp32 operand x is split into two fp16 numbers: h = fp16(x) (round to nearest) and l' = fp16((x - h) * 2^11)
+// (x - h is exact in fp32; the scale keeps l' a normal fp16 number whenever h is one), 22-23 significand bits together.
+// A product a * b is then h_a h_b + 2^-11 (h_a l'_b + l'_a h_b) + 2^-22 l'_a l'_b: the first three terms run on
+// v_mfma_f32_16x16x32_f16 -- hh into one fp32 accumulator set, the two cross terms into a second one that is folded in
+// with one fma by 2^-11 after the K loop -- and the last one (below one fp32 ulp of the product) is dropped.  Three
+// fp16 MFMAs per K = 32 step; round 1's exact three-way bf16 split needed six (hh hm mh mm hl lh) and was pinned at
+// the power-limited rate of the matrix pipe on toggling operands, so halving the MFMA count is worth 1.35-1.47x on the
+// dense1 shapes (tools/ubench/gemm_f16x3.hip: 211-238 against 155-161 TFLOP/s of fp32 work, random data) with a
+// SMALLER error against a double-precision reference (rms relative to sum|a||b| 0.9-1.1e-8 against 2.0-2.1e-8; a plain
+// fp32 fma chain: 2.5e-8).
+// Range.  fp16 holds 2^-14 .. 65504 at full precision; the matrix pipe keeps subnormal inputs (checked in the same
+// microbenchmark), so smaller operands degrade gracefully (absolute error 2^-36 per element, i.e. full precision for
+// every element within 2^-20 of the tensor's largest when that is ~2^6) and an operand above 65504 becomes inf.
+// Forward operands (activations, weights) sit inside that range by themselves; the backward pass is linear in the head
+// gradients, which are scaled by a power of two chosen per update (net_train.inc: loss_scale_kernel) and unscaled
+// exactly when the flat gradient is complete.
 //
 // 256 threads = 4 waves, BK = 32, register prefetch of the next K-tile so the global loads fly under the MFMAs.  LDS
-// holds three bf16 planes per operand in 64-byte rows with an XOR swizzle of the 16-byte chunks (kLdh, swz below): an
+// holds two fp16 planes per operand in 64-byte rows with an XOR swizzle of the 16-byte chunks (kLdh, swz below): an
 // MFMA fragment (8 consecutive k of one row) is one conflict-free ds_read_b128 per plane.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -38,7 +47,9 @@ struct epi_row_bits<E, std::void_t<decltype(E::kRowBits)>> : std::bool_constant<
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef GRL_SCHED_FENCE
 #define GRL_SCHED_FENCE __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -538,42 +549,31 @@ __global__ __launch_bounds__(64) void fold_class_final_kernel(const float *__res
     dst[threadIdx.x] += t;
 }
 
-// ---------------------------------------------------------------------------- fp32 operands on the bf16 matrix pipe
-// x = h + m + l exactly: h = the upper 16 bits of x (truncation to bf16), m = the upper 16 bits of x - h, l = x - h - m
-// (<= 8 significant bits are left, so l is a bf16 number too).  Low halves of the returned dwords are garbage; pack2
-// keeps the upper halves only.
-__device__ __forceinline__ void split1(float x, unsigned &h, unsigned &m, unsigned &l) {
-    h = __float_as_uint(x);
-    const float r = x - __uint_as_float(h & 0xffff0000u);
-    m = __float_as_uint(r);
-    l = __float_as_uint(r - __uint_as_float(m & 0xffff0000u));
+// ---------------------------------------------------------------------------- fp32 operands on the fp16 matrix pipe
+// (x, y) -> packed fp16 pairs h = fp16(.), l = fp16((. - h) * 2^11); 3 VALU instructions per element (v_cvt_pk_f16_f32,
+// v_cvt_f32_f16, v_pk_add_f32, v_pk_mul_f32, v_cvt_pk_f16_f32).  Element 0 of a pair is its low half.
+constexpr float kLowScale = 2048.f;
+__device__ __forceinline__ void split2(float x, float y, unsigned &h, unsigned &l) {
+    const f32x2 xy = {x, y};
+    const f16x2 hv = __builtin_convertvector(xy, f16x2);
+    const f32x2 r = {(x - (float)hv[0]) * kLowScale, (y - (float)hv[1]) * kLowScale};
+    const f16x2 lv = __builtin_convertvector(r, f16x2);
+    h = __builtin_bit_cast(unsigned, hv);
+    l = __builtin_bit_cast(unsigned, lv);
 }
-__device__ __forceinline__ unsigned pack2(unsigned lo, unsigned hi) {      // bf16 pair: element 0 = lo's upper half
-    return __builtin_amdgcn_perm(hi, lo, 0x07060302u);
+// four consecutive-k values -> 4 fp16 per plane
+__device__ __forceinline__ void split4(float x0, float x1, float x2, float x3, uint2 &h, uint2 &l) {
+    split2(x0, x1, h.x, l.x);
+    split2(x2, x3, h.y, l.y);
 }
-// four consecutive-k values -> 4 bf16 per plane
-__device__ __forceinline__ void split4(float x0, float x1, float x2, float x3, uint2 &h, uint2 &m, uint2 &l) {
-    unsigned h0, h1, h2, h3, m0, m1, m2, m3, l0, l1, l2, l3;
-    split1(x0, h0, m0, l0);
-    split1(x1, h1, m1, l1);
-    split1(x2, h2, m2, l2);
-    split1(x3, h3, m3, l3);
-    h = make_uint2(pack2(h0, h1), pack2(h2, h3));
-    m = make_uint2(pack2(m0, m1), pack2(m2, m3));
-    l = make_uint2(pack2(l0, l1), pack2(l2, l3));
+// acc += h_a h_b, acl += l'_a h_b + h_a l'_b (acl carries the factor 2^11) on v_mfma_f32_16x16x32_f16: per FLOP the
+// 16x16x32 form draws less power than 32x32x16, and on toggling operands the matrix pipe is power-limited
+__device__ __forceinline__ void mfma_x3(f32x4 &acc, f32x4 &acl, const f16x8 (&a)[2], const f16x8 (&b)[2]) {
+    acl = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[1], b[0], acl, 0, 0, 0);
+    acl = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], b[1], acl, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], b[0], acc, 0, 0, 0);
 }
-// acc += a * b with the six partial products of weight >= 2^-24 (smallest first), on v_mfma_f32_16x16x32_bf16: per FLOP it
-// draws less power than the 32x32x16 form, and on toggling operands the matrix pipe is power-limited (measured with
-// tools/ubench/gemm_x6.hip: 177-196 against 150-155 TFLOP/s of fp32 work on the dense1 shapes)
-__device__ __forceinline__ void mfma_x6(f32x4 &acc, const bf16x8 (&a)[3], const bf16x8 (&b)[3]) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], acc, 0, 0, 0);
-}
-// LDS tiles: [row][32 bf16] = 64-byte rows, no padding.  The 16-byte chunk c (8 consecutive k) of row r is stored at chunk
+// LDS tiles: [row][32 fp16] = 64-byte rows, no padding.  The 16-byte chunk c (8 consecutive k) of row r is stored at chunk
 // position c ^ swz(r), swz = {0,2,3,1}[(r >> 2) & 3].  The MFMA operand map (lane l: row l & 15, k = 8 (l >> 4) .. +7) then
 // reads one ds_read_b128 per plane with the 16 lanes of every service group on 16 distinct 4-bank slots, and the staging
 // stores of gemm_rowk (8 lanes per row, 8 bytes each) cover whole rows: both conflict free (checked by enumeration).
@@ -588,8 +588,8 @@ __global__ __launch_bounds__(256, 2) void gemm_rowk(AG ag, const float *__restri
     constexpr int NA = BM / 32;                       // float4 per thread for the A tile
     constexpr int NB = BN / 32;                       // float4 per thread for the B tile
     static_assert(WGM * WGN == 4 && TM >= 1 && TN >= 1, "4 waves");
-    __shared__ __attribute__((aligned(16))) unsigned short As[3][BM * LDH];      // planes h, m, l
-    __shared__ __attribute__((aligned(16))) unsigned short Bs[3][BN * LDH];
+    __shared__ __attribute__((aligned(16))) unsigned short As[2][BM * LDH];      // planes h, l'
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[2][BN * LDH];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave - wm * WGN;
@@ -652,11 +652,10 @@ __global__ __launch_bounds__(256, 2) void gemm_rowk(AG ag, const float *__restri
     }
 #define GRL_STORE_PLANES(S_, o_, v4_)                                                                      \
     {                                                                                                      \
-        uint2 h_, m_, l_;                                                                                  \
-        split4((v4_).x, (v4_).y, (v4_).z, (v4_).w, h_, m_, l_);                                            \
+        uint2 h_, l_;                                                                                      \
+        split4((v4_).x, (v4_).y, (v4_).z, (v4_).w, h_, l_);                                                \
         *reinterpret_cast<uint2 *>(&S_[0][o_]) = h_;                                                       \
-        *reinterpret_cast<uint2 *>(&S_[1][o_]) = m_;                                                       \
-        *reinterpret_cast<uint2 *>(&S_[2][o_]) = l_;                                                       \
+        *reinterpret_cast<uint2 *>(&S_[1][o_]) = l_;                                                       \
     }
 #define GRL_STORE_TILE()                                                                                   \
     {                                                                                                      \
@@ -673,13 +672,13 @@ __global__ __launch_bounds__(256, 2) void gemm_rowk(AG ag, const float *__restri
         if (NB > 2) GRL_STORE_PLANES(Bs, (trow + 96) * LDH + wo, rb3)                                      \
     }
 
-    f32x4 acc[TM][TN];
+    f32x4 acc[TM][TN], acl[TM][TN];
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
         for (int b = 0; b < TN; ++b)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[a][b][r] = 0.f;
+            for (int r = 0; r < 4; ++r) acc[a][b][r] = acl[a][b][r] = 0.f;
 
     const int nk = K / BK;
     // K-tiles whose tap is outside the image for the WHOLE workgroup are skipped (tile_ok is block-uniform)
@@ -702,24 +701,31 @@ __global__ __launch_bounds__(256, 2) void gemm_rowk(AG ag, const float *__restri
         }
         GRL_SCHED_FENCE
         {   // one K = 32 step per tile
-            bf16x8 bf[TN][3];
+            f16x8 bf[TN][2];
 #pragma unroll
             for (int b = 0; b < TN; ++b)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) bf[b][p] = *reinterpret_cast<const bf16x8 *>(&Bs[p][bro + b * 16 * LDH]);
+                for (int p = 0; p < 2; ++p) bf[b][p] = *reinterpret_cast<const f16x8 *>(&Bs[p][bro + b * 16 * LDH]);
 #pragma unroll
             for (int a = 0; a < TM; ++a) {
-                bf16x8 af[3];
+                f16x8 af[2];
 #pragma unroll
-                for (int p = 0; p < 3; ++p) af[p] = *reinterpret_cast<const bf16x8 *>(&As[p][aro + a * 16 * LDH]);
+                for (int p = 0; p < 2; ++p) af[p] = *reinterpret_cast<const f16x8 *>(&As[p][aro + a * 16 * LDH]);
 #pragma unroll
-                for (int b = 0; b < TN; ++b) mfma_x6(acc[a][b], af, bf[b]);
+                for (int b = 0; b < TN; ++b) mfma_x3(acc[a][b], acl[a][b], af, bf[b]);
             }
         }
         GRL_SCHED_FENCE
         __syncthreads();
         kt = ktn;
     }
+    // the cross terms carry 2^11
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[a][b][r] = __builtin_fmaf(acl[a][b][r], 1.0f / kLowScale, acc[a][b][r]);
     // C/D map of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + reg.  Two passes: all of the epilogue's loads, then
     // the stores (see the epilogue structs).
     const int erow = m0 + wm * WM + 4 * kg, ecol = n0 + wn * WN + l16;
@@ -803,8 +809,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn(AG ag, const float *__restrict
     constexpr int A4 = BM / 4, B4 = BN / 4;           // float4 per reduction row
     constexpr int NA = BK * A4 / 256, NB = BK * B4 / 256;
     static_assert(WGM * WGN == 4 && NA >= 1 && NB >= 1 && NA <= 4 && NB <= 4, "tile size");
-    __shared__ __attribute__((aligned(16))) unsigned short As[3][BM * LDH];
-    __shared__ __attribute__((aligned(16))) unsigned short Bs[3][BN * LDH];
+    __shared__ __attribute__((aligned(16))) unsigned short As[2][BM * LDH];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[2][BN * LDH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave - wm * WGN;
     // all tiles of one row range (grid z) on one XCD, so its L2 serves the re-reads of the same rows (see gemm_rowk)
@@ -867,23 +873,24 @@ __global__ __launch_bounds__(256, 2) void gemm_tn(AG ag, const float *__restrict
     }
     // tile row rho, reduction position m (0..31) -> swizzled LDS offset
 #define GRL_TN_OFF(rho_, m_) ((rho_) * LDH + ((((m_) >> 3) ^ swz(rho_)) << 3) + ((m_) & 7))
-    // one column's NV consecutive-m values -> NV packed bf16 per plane at S[p][o_]
+    // one column's NV consecutive-m values -> NV packed fp16 per plane at S[p][o_]
 #define GRL_STORE_RUN(S_, NV_, o_, r_, comp_)                                                                      \
     {                                                                                                              \
-        unsigned h_[4], m_[4], l_[4];                                                                              \
-        _Pragma("unroll") for (int i = 0; i < NV_; ++i) split1(r_[i].comp_, h_[i], m_[i], l_[i]);                  \
         if (NV_ == 4) {                                                                                            \
-            *reinterpret_cast<uint2 *>(&S_[0][o_]) = make_uint2(pack2(h_[0], h_[1]), pack2(h_[2], h_[3]));         \
-            *reinterpret_cast<uint2 *>(&S_[1][o_]) = make_uint2(pack2(m_[0], m_[1]), pack2(m_[2], m_[3]));         \
-            *reinterpret_cast<uint2 *>(&S_[2][o_]) = make_uint2(pack2(l_[0], l_[1]), pack2(l_[2], l_[3]));         \
-        } else if (NV_ == 2) {                                                                                     \
-            *reinterpret_cast<unsigned *>(&S_[0][o_]) = pack2(h_[0], h_[1]);                                       \
-            *reinterpret_cast<unsigned *>(&S_[1][o_]) = pack2(m_[0], m_[1]);                                       \
-            *reinterpret_cast<unsigned *>(&S_[2][o_]) = pack2(l_[0], l_[1]);                                       \
+            uint2 h_, l_;                                                                                          \
+            split4(r_[0].comp_, r_[1 % NV_].comp_, r_[2 % NV_].comp_, r_[3 % NV_].comp_, h_, l_);                  \
+            *reinterpret_cast<uint2 *>(&S_[0][o_]) = h_;                                                           \
+            *reinterpret_cast<uint2 *>(&S_[1][o_]) = l_;                                                           \
         } else {                                                                                                   \
-            S_[0][o_] = (unsigned short)(h_[0] >> 16);                                                             \
-            S_[1][o_] = (unsigned short)(m_[0] >> 16);                                                             \
-            S_[2][o_] = (unsigned short)(l_[0] >> 16);                                                             \
+            unsigned h_, l_;                                                                                       \
+            split2(r_[0].comp_, r_[1 % NV_].comp_, h_, l_);                                                        \
+            if (NV_ == 2) {                                                                                        \
+                *reinterpret_cast<unsigned *>(&S_[0][o_]) = h_;                                                    \
+                *reinterpret_cast<unsigned *>(&S_[1][o_]) = l_;                                                    \
+            } else {                                                                                               \
+                S_[0][o_] = (unsigned short)(h_ & 0xFFFFu);                                                        \
+                S_[1][o_] = (unsigned short)(l_ & 0xFFFFu);                                                        \
+            }                                                                                                      \
         }                                                                                                          \
     }
 #define GRL_STORE_TILE()                                                                                           \
@@ -910,13 +917,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tn(AG ag, const float *__restrict
         GRL_STORE_RUN(Bs, NB, GRL_TN_OFF(2 * B4 + cb, mb), rb, z)                                                  \
         GRL_STORE_RUN(Bs, NB, GRL_TN_OFF(3 * B4 + cb, mb), rb, w)                                                  \
     }
-    f32x4 acc[TM][TN];
+    f32x4 acc[TM][TN], acl[TM][TN];
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
         for (int b = 0; b < TN; ++b)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[a][b][r] = 0.f;
+            for (int r = 0; r < 4; ++r) acc[a][b][r] = acl[a][b][r] = 0.f;
     const int l16 = lane & 15, kg = lane >> 4;
     const int ro = (kg ^ swz(l16)) << 3;
     const int aro = (wm * WM + l16) * LDH + ro;
@@ -932,24 +939,31 @@ __global__ __launch_bounds__(256, 2) void gemm_tn(AG ag, const float *__restrict
             GRL_LOAD_IDX(mt + 2 * BK)
             GRL_SCHED_FENCE
             {
-                bf16x8 bf[TN][3];
+                f16x8 bf[TN][2];
 #pragma unroll
                 for (int b = 0; b < TN; ++b)
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) bf[b][p] = *reinterpret_cast<const bf16x8 *>(&Bs[p][bro + b * 16 * LDH]);
+                    for (int p = 0; p < 2; ++p) bf[b][p] = *reinterpret_cast<const f16x8 *>(&Bs[p][bro + b * 16 * LDH]);
 #pragma unroll
                 for (int a = 0; a < TM; ++a) {
-                    bf16x8 af[3];
+                    f16x8 af[2];
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) af[p] = *reinterpret_cast<const bf16x8 *>(&As[p][aro + a * 16 * LDH]);
+                    for (int p = 0; p < 2; ++p) af[p] = *reinterpret_cast<const f16x8 *>(&As[p][aro + a * 16 * LDH]);
 #pragma unroll
-                    for (int b = 0; b < TN; ++b) mfma_x6(acc[a][b], af, bf[b]);
+                    for (int b = 0; b < TN; ++b) mfma_x3(acc[a][b], acl[a][b], af, bf[b]);
                 }
             }
             GRL_SCHED_FENCE
             __syncthreads();
         }
     }
+    // the cross terms carry 2^11
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[a][b][r] = __builtin_fmaf(acl[a][b][r], 1.0f / kLowScale, acc[a][b][r]);
     float *out = slab + (long)bz * I * J;
 #pragma unroll
     for (int a = 0; a < TM; ++a)

@@ -109,6 +109,67 @@ def test_conv_gradients_match_oracle(flags):
     assert np.array_equal(first, net.get_grads())
 
 
+@pytest.mark.parametrize("flags", [0, 1])
+def test_gradients_scale_exactly_with_the_loss_terms(flags):
+    """The backward GEMMs run on the fp16 matrix pipe behind a per-pass power-of-two loss scale (net_train.inc): with the entropy
+    term off the gradient is linear in (advantages, values - targets), so inputs 2^-40 or 2^24 times as large -- head gradients of
+    1e-15 or 1e+6, far outside the fp16 range -- must give the 2^k-fold gradient BITWISE, and the float64 oracle's within the
+    usual tolerance."""
+    from goldsrl import _ffi, _ffi_net
+    E = 6
+    eng, net0, p, states, obs = _setup(E, flags=flags)
+    net = _ffi_net.ConvNet(eng, max_chunk_samples=40, reserved=flags, entropy_beta=0.0)
+    net.set_params(net0.get_params())
+    act, adv, y0 = _train_inputs(E)
+    adv = (adv * 50).astype(np.float32)
+    vs = net.predict()["vs"].reshape(-1).astype(np.float32)      # fp32 values as the device computes them
+    dv = (y0 - vs).astype(np.float32)
+    for k in (0, 24):      # against the float64 oracle (at 2^-40 a float32 target rounds to the value itself: policy-only check below)
+        f = np.float32(2.0 ** k)
+        yk = (vs + dv * f).astype(np.float32)
+        stats = net.train_obs(*obs, act, (adv * f).astype(np.float32), yk, lr=0.0, apply_update=False)
+        g = net.get_grads()
+        assert np.isfinite(g).all() and np.isfinite(stats["global_norm"])
+        _, _, _, ref, _ = NN.conv_loss_and_grads(p, states, act.astype(np.float64), (adv * f).astype(np.float64), yk.astype(np.float64), 0.0, 1000.0)
+        got = NN.unflatten_params(g.astype(np.float64))
+        for name, _ in NN.CONV_PARAM_SHAPES:
+            scale = np.abs(ref[name]).max() + 1e-300
+            err = np.abs(got[name] - ref[name]).max() / scale
+            assert err < 3e-4, (k, name, err)
+    # policy part alone (targets = values: no critic gradient): exact 2^k scaling, bit for bit
+    pol = {}
+    for k in (0, -40, 24):
+        f = np.float32(2.0 ** k)
+        net.train_obs(*obs, act, (adv * f).astype(np.float32), vs, lr=0.0, apply_update=False)
+        pol[k] = net.get_grads()
+    assert np.abs(pol[0]).max() > 0
+    assert np.array_equal(pol[-40] * np.float32(2.0 ** 40), pol[0])
+    assert np.array_equal(pol[24] * np.float32(2.0 ** -24), pol[0])
+    net.close()
+
+
+def test_without_the_loss_scale_small_head_gradients_are_lost(monkeypatch):
+    """What the scale is for: GRL_NET_LOSS_SCALE=off runs the same pass with S = 1, and head gradients of 1e-15 underflow the fp16
+    planes of the backward GEMMs (the flat gradient comes out wrong by far more than float32 round-off)."""
+    from goldsrl import _ffi_net
+    E = 6
+    eng, net0, p, states, obs = _setup(E)
+    act, adv, _ = _train_inputs(E)
+    adv = (adv * 50).astype(np.float32)
+    out = {}
+    for mode in ("on", "off"):
+        monkeypatch.setenv("GRL_NET_LOSS_SCALE", mode)
+        net = _ffi_net.ConvNet(eng, max_chunk_samples=40, entropy_beta=0.0)
+        net.set_params(net0.get_params())
+        vs = net.predict()["vs"].reshape(-1).astype(np.float32)
+        net.train_obs(*obs, act, adv, vs, lr=0.0, apply_update=False)
+        g0 = net.get_grads()
+        net.train_obs(*obs, act, (adv * np.float32(2.0 ** -40)).astype(np.float32), vs, lr=0.0, apply_update=False)
+        out[mode] = np.abs(net.get_grads() * np.float32(2.0 ** 40) - g0).max() / np.abs(g0).max()
+        net.close()
+    assert out["on"] == 0.0 and out["off"] > 1e-3, out
+
+
 @pytest.mark.parametrize("A", [1, 3, 4])
 def test_num_actions_is_a_parameter_of_the_heads(A):
     """ConvSingleAgentPolicyNetwork takes conf['num_actions'] (policy_v_network.py:10,40-43; the reference's own shape test
@@ -520,8 +581,9 @@ def test_split_gradient_step_equals_fused_and_supports_host_exchange():
 
 
 def test_forward_error_is_at_the_float32_level():
-    """The GEMMs run fp32 operands as three exact bf16 terms with six of the nine partial products (net_gemm.h): the
-    result must be as close to the float64 oracle as a plain float32 evaluation of the same net (numpy/BLAS float32)."""
+    """The GEMMs run fp32 operands as two fp16 terms (22-23 significand bits) with three of the four partial products
+    (net_gemm.h): the result must be as close to the float64 oracle as a plain float32 evaluation of the same net
+    (numpy/BLAS float32)."""
     E = 6
     eng, net, p, states, obs = _setup(E)
     out = net.predict()
