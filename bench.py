@@ -41,11 +41,12 @@ VALU_LANE_INSTR_PEAK = 256 * 4 * 16 * 2.4e9
 SWARM_PAIRS_PER_ENV_STEP = 7200      # pair interactions (6400 locust-locust + 800 agent-locust)
 HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3         # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
-MFMA_BF16_PEAK_TFLOPS = 2516.6       # MI355X_MICROARCH.md: dense bf16 matrix peak (v_mfma_f32_16x16x32_bf16, 16 cycles each)
-# the GEMMs split every fp32 operand exactly into three bf16 terms and issue SIX bf16 MFMAs per fp32 product block
-# (net_gemm.h), so the matrix pipe bounds the fp32-equivalent rate at 2516.6 / 6
-BF16_PRODUCTS_PER_FP32 = 6
-MFMA_X6_PEAK_TFLOPS = MFMA_BF16_PEAK_TFLOPS / BF16_PRODUCTS_PER_FP32
+MFMA_F16_PEAK_TFLOPS = 2516.6        # MI355X_MICROARCH.md: dense fp16 / bf16 matrix peak (v_mfma_f32_16x16x32_f16, 16 cycles each)
+# the GEMMs split every fp32 operand into two fp16 terms (22-23 significand bits) and issue THREE fp16 MFMAs per fp32 product
+# block (net_gemm.h), so the matrix pipe bounds the fp32-equivalent rate at 2516.6 / 3.  (Rounds 1-2 used an exact three-way
+# bf16 split with SIX products: peak 419.4, same kernels otherwise -- the fraction is not comparable across that change.)
+F16_PRODUCTS_PER_FP32 = 3
+MFMA_X3_PEAK_TFLOPS = MFMA_F16_PEAK_TFLOPS / F16_PRODUCTS_PER_FP32
 GEMM_TRAFFIC_FILE = "r02_gemm_traffic.json"   # PMC pass of the GEMM kernels (tools/run_prof.sh); refreshed per round
 
 
@@ -392,14 +393,17 @@ def main():
                 with open(gpath) as f:
                     gtraffic = json.load(f).get("hbm_bytes_per_launch")
             out["roofline"] = {"bound": "mfma",
-                               "kernel": "gemm_rowk / gemm_tn (fp32 implicit GEMMs: operands split exactly into 3 bf16 terms, "
-                                         "6 v_mfma_f32_16x16x32_bf16 per 16x16 tile and K=32 step, fp32 accumulation)",
-                               "achieved": ach, "peak": MFMA_X6_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_X6_PEAK_TFLOPS,
+                               "kernel": "gemm_rowk / gemm_tn (fp32 implicit GEMMs: operands split into 2 fp16 terms, "
+                                         "3 v_mfma_f32_16x16x32_f16 per 16x16 tile and K=32 step, fp32 accumulation)",
+                               "achieved": ach, "peak": MFMA_X3_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_X3_PEAK_TFLOPS,
                                "peak_note": "achieved counts ALGORITHMIC fp32 FLOPs (2*M*N*K of the work actually executed); peak = "
-                                            "dense bf16 MFMA peak %.1f / %d bf16 products per fp32 product.  The executed bf16 MFMA "
-                                            "rate is %d x achieved; the fp32 MFMA peak (v_mfma_f32_32x32x2_f32) would be %.1f" % (
-                                                MFMA_BF16_PEAK_TFLOPS, BF16_PRODUCTS_PER_FP32, BF16_PRODUCTS_PER_FP32, MFMA_F32_PEAK_TFLOPS),
-                               "executed_bf16_tflops": ach * BF16_PRODUCTS_PER_FP32,
+                                            "dense fp16 MFMA peak %.1f / %d fp16 products per fp32 product (round 2's six-product bf16 "
+                                            "form had peak %.1f: halving the MFMA count doubled the peak this fraction is taken of).  "
+                                            "The executed fp16 MFMA rate is %d x achieved; the fp32 MFMA peak "
+                                            "(v_mfma_f32_32x32x2_f32) would be %.1f" % (
+                                                MFMA_F16_PEAK_TFLOPS, F16_PRODUCTS_PER_FP32, MFMA_F16_PEAK_TFLOPS / 6, F16_PRODUCTS_PER_FP32,
+                                                MFMA_F32_PEAK_TFLOPS),
+                               "executed_f16_tflops": ach * F16_PRODUCTS_PER_FP32,
                                "vs_fp32_mfma_peak": ach / MFMA_F32_PEAK_TFLOPS,
                                "traffic": gtraffic, "launches": launches, "gemm_ms_total": ms,
                                "gemm_share_of_step": (ms * 1e-3) / gemm_step_s if gemm_step_s else None,
@@ -408,7 +412,7 @@ def main():
                                            "to four streams (GRL_NET_F_SINGLE_STREAM off)" % (gemm_step_s * 1e3 if gemm_step_s else 0.0),
                                "flops_per_launch_avg": flops / max(launches, 1),
                                "by_family": {k: {"launches": v[0], "ms": v[1], "achieved": v[2] / (v[1] * 1e-3) / 1e12 if v[1] > 0 else 0.0,
-                                                 "frac": (v[2] / (v[1] * 1e-3) / 1e12 / MFMA_X6_PEAK_TFLOPS) if v[1] > 0 else 0.0}
+                                                 "frac": (v[2] / (v[1] * 1e-3) / 1e12 / MFMA_X3_PEAK_TFLOPS) if v[1] > 0 else 0.0}
                                              for k, v in gemm_tags.items()}}
             out["roofline_env_step"] = env_roof
         else:

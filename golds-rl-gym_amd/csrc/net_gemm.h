@@ -802,7 +802,7 @@ __global__ __launch_bounds__(256, 2) void gemm_rowk(AG ag, const float *__restri
 // NA consecutive rows of the same four columns and writes each column's NA values (packed bf16) to the transposed LDS
 // tile [column][m].  Column 4*c4 + j sits in LDS row j*(BM/4) + c4, which spreads a store's lanes over the banks; the
 // epilogue undoes the permutation.
-template <int BM, int BN, int WGM, int WGN, class AG, bool XCD_ORDER = true>
+template <int BM, int BN, int WGM, int WGN, class AG, int XCD_ORDER = 1>
 __global__ __launch_bounds__(256, 2) void gemm_tn(AG ag, const float *__restrict__ dY, int J, int mc, float *__restrict__ slab) {
     constexpr int BK = 32, LDH = kLdh;
     constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 16, TN = WN / 16;
@@ -813,9 +813,23 @@ __global__ __launch_bounds__(256, 2) void gemm_tn(AG ag, const float *__restrict
     __shared__ __attribute__((aligned(16))) unsigned short Bs[2][BN * LDH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave - wm * WGN;
-    // all tiles of one row range (grid z) on one XCD, so its L2 serves the re-reads of the same rows (see gemm_rowk)
+    // XCD_ORDER 1: all tiles of one row range (grid z) on one XCD, so its L2 serves the re-reads of the same rows (see gemm_rowk).
+    // XCD_ORDER 2: inside a row range the J tiles of one I tile share an XCD (runs of 8 I tiles are transposed), so the A columns
+    // of an I tile are fetched into one L2 instead of gridDim.y of them -- for row ranges too large for one L2 (dense1 patch).
     int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-    if (XCD_ORDER) {
+    if (XCD_ORDER == 2) {
+        const int nx = gridDim.x, ny = gridDim.y, l = by * nx + bx, g = l / (8 * ny);
+        if ((g + 1) * 8 <= nx) {
+            const int r = l - g * 8 * ny;
+            bx = g * 8 + (r & 7);
+            by = r >> 3;
+        } else {      // the last partial run of I tiles, compacted: l - 8 ny g indexes (bx - 8 g, by) with bx fastest
+            const int r = l - g * 8 * ny, w = nx - g * 8;
+            by = r / w;
+            bx = g * 8 + (r - by * w);
+        }
+    }
+    if (XCD_ORDER == 1) {
         const int nx = gridDim.x, T = nx * gridDim.y, L = bz * T + by * nx + bx, g = L / (8 * T);
         if ((g + 1) * 8 <= (int)gridDim.z) {
             const int l = L - g * 8 * T, t = l >> 3;

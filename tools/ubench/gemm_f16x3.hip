@@ -63,13 +63,22 @@ template <int BM, int BN, int WGM, int WGN, int MODE>
 __global__ __launch_bounds__(256, 2) void rowk(const float *__restrict__ A, const float *__restrict__ Bt, const unsigned short *__restrict__ Bp,
                                                float *__restrict__ C, int M, int N, int K) {
     constexpr int BK = 32, LDH = 32, NP = MODE == 0 ? 3 : 2;
-    constexpr bool TWO = MODE == 1 || MODE == 3;
+    constexpr bool TWO = MODE == 1 || MODE == 3 || MODE == 6 || MODE == 7;
     constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 16, TN = WN / 16, NA = BM / 32, NB = BN / 32;
     __shared__ __attribute__((aligned(16))) unsigned short As[NP][BM * LDH];
     __shared__ __attribute__((aligned(16))) unsigned short Bs[NP][BN * LDH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave - wm * WGN;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    int bx_ = blockIdx.x, by_ = blockIdx.y;
+    if (MODE == 7) {      // XCD x takes M-tile 8g + x with all its N tiles (gemm_rowk's order)
+        const int nx = gridDim.x, L = by_ * nx + bx_, g = L / (8 * nx);
+        if ((g + 1) * 8 <= (int)gridDim.y) {
+            const int l = L - g * 8 * nx;
+            by_ = g * 8 + (l & 7);
+            bx_ = l >> 3;
+        }
+    }
+    const int m0 = by_ * BM, n0 = bx_ * BN;
     const int trow = tid >> 3, tk4 = (tid & 7) * 4;
     const int wo = (((tk4 >> 3) ^ swz(trow)) << 3) + (tk4 & 4);
     const float *arow = A + (long)(m0 + trow) * K + tk4;
@@ -81,7 +90,7 @@ __global__ __launch_bounds__(256, 2) void rowk(const float *__restrict__ A, cons
     const int po = prow * LDH + ((pc ^ swz(prow)) << 3);
     uint4 pb00, pb01, pb10, pb11;
     pb00 = pb01 = pb10 = pb11 = make_uint4(0, 0, 0, 0);
-    static_assert(BN == 128, "two 64-row halves");
+    static_assert(BN == 128 || MODE != 3, "two 64-row halves");
     float4 ra[NA], rb[NB];
 #define LOAD(kt_)                                                                                                                      \
     {                                                                                                                                  \
@@ -145,7 +154,13 @@ __global__ __launch_bounds__(256, 2) void rowk(const float *__restrict__ A, cons
             }
         }
         __syncthreads();
-        LOAD(kt + 1 < nk ? kt + 1 : kt)
+        if (MODE != 6) LOAD(kt + 1 < nk ? kt + 1 : kt)
+        if (MODE == 6) {      // opaque to the optimiser: the split stays in the loop, only the loads are gone
+#pragma unroll
+            for (int i = 0; i < NA; ++i) asm volatile("" : "+v"(ra[i].x), "+v"(ra[i].y), "+v"(ra[i].z), "+v"(ra[i].w));
+#pragma unroll
+            for (int i = 0; i < NB; ++i) asm volatile("" : "+v"(rb[i].x), "+v"(rb[i].y), "+v"(rb[i].z), "+v"(rb[i].w));
+        }
         __builtin_amdgcn_sched_barrier(0);
         if (MODE == 0) {
             bf16x8 bf[TN][3];
@@ -207,6 +222,201 @@ __global__ __launch_bounds__(256, 2) void rowk(const float *__restrict__ A, cons
                 if (TWO) v = __builtin_fmaf(acl[a][b][r], 1.f / 2048.f, v);
                 if (row < M && col < N) C[(long)row * N + col] = v;
             }
+}
+
+
+// ---------------------------------------------------------------------------- software-pipelined form
+// Two LDS buffers and ONE barrier per K-tile: while the MFMAs of tile kt run out of buffer kt & 1, the same wave splits the
+// registers holding tile kt+1 into buffer (kt+1) & 1 (the VALU work sits in the shadow of the matrix pipe instead of in its own
+// phase between two barriers), then issues the global loads of tile kt+2.  PIPE = 1 pins the interleaving with
+// sched_group_barrier (one MFMA, then a few VALU / DS instructions), PIPE = 0 leaves it to the compiler.
+template <int BM, int BN, int WGM, int WGN, int PIPE>
+__global__ __launch_bounds__(256, 2) void rowk_db(const float *__restrict__ A, const float *__restrict__ Bt, float *__restrict__ C, int M, int N, int K) {
+    constexpr int BK = 32, LDH = 32;
+    constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 16, TN = WN / 16, NA = BM / 32, NB = BN / 32;
+    constexpr int ABUF = 2 * BM * LDH, BBUF = 2 * BN * LDH;      // one buffer = two planes
+    __shared__ __attribute__((aligned(16))) unsigned short As[2 * ABUF];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[2 * BBUF];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave - wm * WGN;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int trow = tid >> 3, tk4 = (tid & 7) * 4;
+    const int wo = (((tk4 >> 3) ^ swz(trow)) << 3) + (tk4 & 4);
+    const float *arow = A + (long)(m0 + trow) * K + tk4;
+    const float *brow = Bt + (long)(n0 + trow) * K + tk4;
+    const int l16 = lane & 15, kg = lane >> 4;
+    float4 ra[NA], rb[NB];
+#define LOADT(kt_)                                                                                                                     \
+    {                                                                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const float4 *>(arow + (long)32 * i * K + (kt_) * BK); \
+        _Pragma("unroll") for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const float4 *>(brow + (long)32 * i * K + (kt_) * BK); \
+    }
+#define STORET(buf_)                                                                                               \
+    {                                                                                                              \
+        _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                           \
+            const int o = (buf_) * ABUF + (trow + 32 * i) * LDH + wo;                                              \
+            uint2 h, l;                                                                                            \
+            hsplit4(ra[i], h, l);                                                                                  \
+            *reinterpret_cast<uint2 *>(&As[o]) = h;                                                                \
+            *reinterpret_cast<uint2 *>(&As[o + BM * LDH]) = l;                                                     \
+        }                                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                           \
+            const int o = (buf_) * BBUF + (trow + 32 * i) * LDH + wo;                                              \
+            uint2 h, l;                                                                                            \
+            hsplit4(rb[i], h, l);                                                                                  \
+            *reinterpret_cast<uint2 *>(&Bs[o]) = h;                                                                \
+            *reinterpret_cast<uint2 *>(&Bs[o + BN * LDH]) = l;                                                     \
+        }                                                                                                          \
+    }
+    f32x4 acc[TM][TN], acl[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[a][b][r] = acl[a][b][r] = 0.f;
+    const int rofs = (kg ^ swz(l16)) << 3;
+    const int aro = (wm * WM + l16) * LDH + rofs, bro = (wn * WN + l16) * LDH + rofs;
+    const int nk = K / BK;
+    LOADT(0)
+    STORET(0)
+    LOADT(nk > 1 ? 1 : 0)
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const unsigned short *Ac = As + cur * ABUF, *Bc = Bs + cur * BBUF;
+        f16x8 bf[TN][2];
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) bf[b][p] = *reinterpret_cast<const f16x8 *>(&Bc[p * BN * LDH + bro + b * 16 * LDH]);
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+            f16x8 af[2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) af[p] = *reinterpret_cast<const f16x8 *>(&Ac[p * BM * LDH + aro + a * 16 * LDH]);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                acl[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[1], bf[b][0], acl[a][b], 0, 0, 0);
+                acl[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[0], bf[b][1], acl[a][b], 0, 0, 0);
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[0], bf[b][0], acc[a][b], 0, 0, 0);
+            }
+            if (a == 1) {      // the staging of tile kt+1 is split over the MFMA block's first half ...
+                if (kt + 1 < nk) STORET(cur ^ 1)
+            }
+            if (a == 2) {      // ... and the loads of tile kt+2 follow as soon as the registers are free
+                LOADT(kt + 2 < nk ? kt + 2 : kt)
+            }
+        }
+        if (PIPE == 1) {
+            // 48 MFMAs; ~100 VALU, 16 DS writes, 16 DS reads, 8 VMEM reads to place between them
+#pragma unroll
+            for (int i = 0; i < TM * TN * 3; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);      // up to three VALU
+                __builtin_amdgcn_sched_group_barrier(0x300, 1, 0);      // one DS read or write
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // one VMEM read
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int row = m0 + wm * WM + a * 16 + 4 * kg + r;
+                int col = n0 + wn * WN + b * 16 + l16;
+                if (row < M && col < N) C[(long)row * N + col] = __builtin_fmaf(acl[a][b][r], 1.f / 2048.f, acc[a][b][r]);
+            }
+#undef LOADT
+#undef STORET
+}
+
+
+// ---------------------------------------------------------------------------- A operand straight into the MFMA registers
+// With the four waves of a workgroup stacked along M (256 x 64 tile) no two waves share a row of A, so A needs no LDS at all:
+// lane (row l16, k group kg) of a wave loads the 8 consecutive k of its row (32 bytes) for each of its four 16-row tiles -- the
+// MFMA operand layout -- and splits them in registers.  Only the 64 weight rows go through LDS (written once, read by all four
+// waves): 40 KB of LDS traffic per K-tile instead of 96 KB for the same 1 MFLOP.
+template <int TN_>
+__global__ __launch_bounds__(256, 2) void rowk_adirect(const float *__restrict__ A, const float *__restrict__ Bt, float *__restrict__ C, int M, int N, int K) {
+    constexpr int BK = 32, LDH = 32, BM = 256, BN = 16 * TN_, TM = 4, TN = TN_, NB = BN / 32;
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[2][BN * LDH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * BM + wave * 64, n0 = blockIdx.x * BN;
+    const int trow = tid >> 3, tk4 = (tid & 7) * 4;
+    const int wo = (((tk4 >> 3) ^ swz(trow)) << 3) + (tk4 & 4);
+    const int l16 = lane & 15, kg = lane >> 4;
+    const float *arow = A + (long)(m0 + l16) * K + kg * 8;
+    const float *brow = Bt + (long)(n0 + trow) * K + tk4;
+    float4 ra[TM][2], rb[NB];
+#define LOADT(kt_)                                                                                                                     \
+    {                                                                                                                                  \
+        _Pragma("unroll") for (int a = 0; a < TM; ++a) {                                                                               \
+            ra[a][0] = *reinterpret_cast<const float4 *>(arow + (long)16 * a * K + (kt_) * BK);                                        \
+            ra[a][1] = *reinterpret_cast<const float4 *>(arow + (long)16 * a * K + (kt_) * BK + 4);                                    \
+        }                                                                                                                              \
+        _Pragma("unroll") for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const float4 *>(brow + (long)32 * i * K + (kt_) * BK); \
+    }
+    f32x4 acc[TM][TN], acl[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[a][b][r] = acl[a][b][r] = 0.f;
+    const int bro = l16 * LDH + ((kg ^ swz(l16)) << 3);
+    const int nk = K / BK;
+    LOADT(0)
+    for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int o = (trow + 32 * i) * LDH + wo;
+            uint2 h, l;
+            hsplit4(rb[i], h, l);
+            *reinterpret_cast<uint2 *>(&Bs[0][o]) = h;
+            *reinterpret_cast<uint2 *>(&Bs[1][o]) = l;
+        }
+        f16x8 af[TM][2];
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+            uint2 h0, l0, h1, l1;
+            hsplit4(ra[a][0], h0, l0);
+            hsplit4(ra[a][1], h1, l1);
+            af[a][0] = __builtin_bit_cast(f16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));
+            af[a][1] = __builtin_bit_cast(f16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
+        }
+        __syncthreads();
+        LOADT(kt + 1 < nk ? kt + 1 : kt)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            f16x8 bf[2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) bf[p] = *reinterpret_cast<const f16x8 *>(&Bs[p][bro + b * 16 * LDH]);
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                acl[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[a][1], bf[0], acl[a][b], 0, 0, 0);
+                acl[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[a][0], bf[1], acl[a][b], 0, 0, 0);
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[a][0], bf[0], acc[a][b], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int row = m0 + a * 16 + 4 * kg + r;
+                int col = n0 + b * 16 + l16;
+                if (row < M && col < N) C[(long)row * N + col] = __builtin_fmaf(acl[a][b][r], 1.f / 2048.f, acc[a][b][r]);
+            }
+#undef LOADT
 }
 
 static double err_vs_double(const std::vector<float> &A, const std::vector<float> &B, const std::vector<float> &C, int M, int N, int K, double *rms_out) {
@@ -278,6 +488,35 @@ static void variant(const char *name, const float *A, const float *B, const unsi
     fflush(stdout);
 }
 
+template <int K_>
+static void variant_x(const char *name, const float *A, const float *B, const unsigned short *Bp, float *C, int M, int N, int K, const std::vector<float> &hA,
+                      const std::vector<float> &hB, std::vector<float> &hC) {
+    const double flops = 2.0 * M * N * K;
+    dim3 grid((N + 63) / 64, (M + 255) / 256);
+    (void)hipMemset(C, 0, (size_t)M * N * 4);
+    float ms = time_ms([&] {
+        if (K_ == 0) hipLaunchKernelGGL((rowk<256, 64, 4, 1, 1>), grid, dim3(256), 0, 0, A, B, Bp, C, M, N, K);
+        else hipLaunchKernelGGL((rowk_adirect<4>), grid, dim3(256), 0, 0, A, B, C, M, N, K);
+    }, 20);
+    (void)hipMemcpy(hC.data(), C, hC.size() * 4, hipMemcpyDeviceToHost);
+    double rms, w = err_vs_double(hA, hB, hC, M, N, K, &rms);
+    printf("M %6d N %4d K %4d  %-44s %8.3f ms %7.1f TF   err/sum|ab| worst %.3g rms %.3g\n", M, N, K, name, ms, flops / ms / 1e9, w, rms);
+    fflush(stdout);
+}
+
+template <int PIPE>
+static void variant_db(const char *name, const float *A, const float *B, float *C, int M, int N, int K, const std::vector<float> &hA,
+                       const std::vector<float> &hB, std::vector<float> &hC) {
+    const double flops = 2.0 * M * N * K;
+    dim3 grid((N + 127) / 128, (M + 127) / 128);
+    (void)hipMemset(C, 0, (size_t)M * N * 4);
+    float ms = time_ms([&] { hipLaunchKernelGGL((rowk_db<128, 128, 2, 2, PIPE>), grid, dim3(256), 0, 0, A, B, C, M, N, K); }, 20);
+    (void)hipMemcpy(hC.data(), C, hC.size() * 4, hipMemcpyDeviceToHost);
+    double rms, w = err_vs_double(hA, hB, hC, M, N, K, &rms);
+    printf("M %6d N %4d K %4d  %-44s %8.3f ms %7.1f TF   err/sum|ab| worst %.3g rms %.3g\n", M, N, K, name, ms, flops / ms / 1e9, w, rms);
+    fflush(stdout);
+}
+
 static void run(int M, int N, int K, float amag, float bmag) {
     std::vector<float> hA((long)M * K), hB((long)N * K), hC((long)M * N);
     unsigned s = 12345u;
@@ -296,6 +535,12 @@ static void run(int M, int N, int K, float amag, float bmag) {
     variant<0>("six bf16 products (today)", A, B, Bp, C, M, N, K, hA, hB, hC);
     variant<1>("three fp16 products, scaled low plane", A, B, Bp, C, M, N, K, hA, hB, hC);
     variant<3>("three fp16 products, weights pre-split", A, B, Bp, C, M, N, K, hA, hB, hC);
+    variant<7>("three fp16 products, XCD-aware tile order", A, B, Bp, C, M, N, K, hA, hB, hC);
+    variant<6>("(speed only) no global loads in the loop", A, B, Bp, C, M, N, K, hA, hB, hC);
+    variant_x<0>("three fp16, 256x64 tile, both through LDS", A, B, Bp, C, M, N, K, hA, hB, hC);
+    variant_x<1>("three fp16, 256x64 tile, A direct to registers", A, B, Bp, C, M, N, K, hA, hB, hC);
+    variant_db<0>("three fp16, two LDS buffers, one barrier", A, B, C, M, N, K, hA, hB, hC);
+    variant_db<1>("  + pinned MFMA / VALU interleaving", A, B, C, M, N, K, hA, hB, hC);
     variant<2>("(speed only) three products, one accumulator", A, B, Bp, C, M, N, K, hA, hB, hC);
     (void)hipMemset(A, 0, hA.size() * 4);
     std::vector<float> z(hA.size(), 0.f);
