@@ -10,6 +10,12 @@
  *   conv1_w[8,8,3,32] conv1_b conv2_w[4,4,32,64] conv2_b conv3_w[3,3,64,64] conv3_b dense1_w[3136,512]
  *   dense1_b dense2_w[512,256] dense2_b pol1_w[256,512] pol1_b mu_w[512,A] mu_b[A] sigma_w[512,A] sigma_b[A]
  *   v1_w[256,512] v1_b v2_w[512,256] v2_b v3_w[256,1] v3_b          (2 210 213 floats at A = num_actions = 2)
+ * Arithmetic: float32 in, float32 out, float32 accumulation, as the reference's TF graph.  conv2, conv3 and the dense layers run
+ * on the fp16 matrix pipe with every fp32 operand split into two fp16 terms (22-23 significand bits; csrc/net_gemm.h), which
+ * measures closer to a float64 evaluation than a plain float32 one.  Range contract of that form: activations and weights
+ * below 65 504 in magnitude (larger ones become inf and show as a non-finite loss / global_norm in the statistics; nothing is
+ * clamped); gradient passes pick an exact power-of-two loss scale per call, so advantages / targets of any float32 magnitude
+ * are fine.  GRL_NET_LOSS_SCALE=off in the environment disables that scale (diagnostic only).
  */
 #ifndef GOLDSRL_NET_H
 #define GOLDSRL_NET_H
