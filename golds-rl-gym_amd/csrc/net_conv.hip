@@ -121,7 +121,8 @@ struct grl_net : NetLane {
     int expand2_gemm, ctiles;  // conv2's per-agent corrections as a class-sorted GEMM (default) or the LDS-resident kernel (GRL_NET_EXPAND2=lds)
     float *w2corr;             // [4 classes][576][128] kernel slices of that GEMM, rebuilt with the transposes
     grl::HeadOff ho;           // offsets of the head / value parameters for this net's num_actions
-    int npad, ptiles, pslices, pslice_rows, pwgrad_xcd, pdgrad_xcd;      // dense1 patch weight gradient: slice length and tile order (tuning knobs)
+    int npad, ptiles, pslices, pslice_rows, pwgrad_xcd, pdgrad_xcd;
+    int tn_wgs, tn_wgs_dense;  // workgroups a split-M weight-gradient launch aims at (slab count = tn_wgs / tiles)      // dense1 patch weight gradient: slice length and tile order (tuning knobs)
     size_t slab_floats;
     float *stats;              // device: [0..4] loss parts / norm / clip factor, [8..9] loss scale S and 1/S, [10] bits of the head-gradient bound
     // rollout storage (allocated by grl_net_rollout)
@@ -688,6 +689,9 @@ int grl_net_create(grl_handle *h, const grl_net_config *cfg, grl_net **out) {
     if (const char *e = getenv("GRL_PATCH_SLICE")) { const int v = atoi(e); if (v == 256 || v == 512 || v == 1024 || v == 2048) n->pslice_rows = v; }
     if (const char *e = getenv("GRL_PATCH_WGRAD_XCD")) n->pwgrad_xcd = atoi(e);
     n->pdgrad_xcd = 0;
+    n->tn_wgs = 1024; n->tn_wgs_dense = 512;
+    if (const char *e = getenv("GRL_TN_WGS")) { const int v = atoi(e); if (v >= 256 && v <= 4096) n->tn_wgs = v; }
+    if (const char *e = getenv("GRL_TN_WGS_DENSE")) { const int v = atoi(e); if (v >= 128 && v <= 4096) n->tn_wgs_dense = v; }
     if (const char *e = getenv("GRL_PATCH_DGRAD_XCD")) n->pdgrad_xcd = atoi(e) != 0;
     n->pslices = (int)((c + n->pslice_rows - 1) / n->pslice_rows) + 9;
     n->npad = (int)((c + 255) / 256 * 256);
