@@ -526,7 +526,7 @@ static int forward_chunk(grl_net *net, const uint8_t *lb, const uint8_t *ab, con
         GatherConv2 g{net->a1, n * 81};
         EpiBiasAct e{net->a2, 64, P + ConvOffsets::c2b, ACT_RELU};
         GemmTimer t(net, 2.0 * n * 81 * 512 * 64);
-        hipLaunchKernelGGL((gemm_rowk<256, 64, 4, 1, GatherConv2, EpiBiasAct>), dim3(1, (n * 81 + 255) / 256), dim3(256), 0, st,
+        hipLaunchKernelGGL((gemm_rowk<256, 64, kW256M, kW256N, GatherConv2, EpiBiasAct>), dim3(1, (n * 81 + 255) / 256), dim3(64 * kW256M * kW256N), 0, st,
                            g, PT + ConvOffsets::c2w, 512, 64, e);
     }
     }
@@ -537,7 +537,7 @@ static int forward_chunk(grl_net *net, const uint8_t *lb, const uint8_t *ab, con
         GatherConv3 g{net->a2, n * 49};
         EpiBiasAct e{net->a3, 64, P + ConvOffsets::c3b, ACT_RELU};
         GemmTimer t(net, 2.0 * n * 49 * 576 * 64);
-        hipLaunchKernelGGL((gemm_rowk<256, 64, 4, 1, GatherConv3, EpiBiasAct>), dim3(1, (n * 49 + 255) / 256), dim3(256), 0, st,
+        hipLaunchKernelGGL((gemm_rowk<256, 64, kW256M, kW256N, GatherConv3, EpiBiasAct>), dim3(1, (n * 49 + 255) / 256), dim3(64 * kW256M * kW256N), 0, st,
                            g, PT + ConvOffsets::c3w, 576, 64, e);
     }
     net->prof_tag_cur = net->shared_trunk ? PT_DENSE_FWD : PT_PER_AGENT;
@@ -545,7 +545,7 @@ static int forward_chunk(grl_net *net, const uint8_t *lb, const uint8_t *ab, con
         DenseRows g{in, n, K, K};
         EpiBiasAct e{out, N, b, ACT_RELU};
         GemmTimer t(net, 2.0 * n * K * N);
-        hipLaunchKernelGGL((gemm_rowk<128, 128, 2, 2, DenseRows, EpiBiasAct>), dim3(N / 128, (n + 127) / 128), dim3(256), 0, st, g,
+        hipLaunchKernelGGL((gemm_rowk<128, 128, kW128M, kW128N, DenseRows, EpiBiasAct>), dim3(N / 128, (n + 127) / 128), dim3(64 * kW128M * kW128N), 0, st, g,
                            w, K, N, e);
     };
     if (!net->shared_trunk) dense(net->a3, 3136, PT + ConvOffsets::d1w, P + ConvOffsets::d1b, 512, net->d1);

@@ -578,16 +578,23 @@ __device__ __forceinline__ void mfma_x3(f32x4 &acc, f32x4 &acl, const f16x8 (&a)
 // reads one ds_read_b128 per plane with the 16 lanes of every service group on 16 distinct 4-bank slots, and the staging
 // stores of gemm_rowk (8 lanes per row, 8 bytes each) cover whole rows: both conflict free (checked by enumeration).
 constexpr int kLdh = 32;
+// wave layouts of the two large tile shapes (WGM x WGN waves; 4 x 2 and 8 x 1: eight waves with 32 x 64 wave tiles)
+constexpr int kW128M = 4, kW128N = 2, kW256M = 8, kW256N = 1;
 __device__ __forceinline__ int swz(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }
 
 // ---------------------------------------------------------------------------- C = A(rowk) * Bt^T
+// Four or eight waves per workgroup (WGM x WGN).  The eight-wave forms keep a tile's bytes per FLOP and halve the wave tile
+// (32 x 64: 64 accumulator registers instead of 128), so four waves fit a SIMD instead of two: with three MFMAs per product the
+// loop waits on its loads and barriers more than on the matrix pipe, and more resident waves cover those waits (+4-18 % on the
+// dense1 shapes, most on short K: tools/ubench/gemm_f16x3.hip).  The second launch bound is waves per SIMD (HIP-Clang): two
+// workgroups per CU either way, i.e. a 256- or 128-register budget.
 template <int BM, int BN, int WGM, int WGN, class AG, class Epi, bool XCD_ORDER = true>
-__global__ __launch_bounds__(256, 2) void gemm_rowk(AG ag, const float *__restrict__ Bt, int ldb, int N, Epi epi) {
-    constexpr int BK = 32, LDH = kLdh;
+__global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void gemm_rowk(AG ag, const float *__restrict__ Bt, int ldb, int N, Epi epi) {
+    constexpr int BK = 32, LDH = kLdh, NT = 64 * WGM * WGN, RPP = NT / 8;          // RPP: tile rows staged per pass (8 threads per row)
     constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 16, TN = WN / 16;       // 16x16 MFMA tiles per wave
-    constexpr int NA = BM / 32;                       // float4 per thread for the A tile
-    constexpr int NB = BN / 32;                       // float4 per thread for the B tile
-    static_assert(WGM * WGN == 4 && TM >= 1 && TN >= 1, "4 waves");
+    constexpr int NA = BM / RPP;                      // float4 per thread for the A tile
+    constexpr int NB = BN / RPP;                      // float4 per thread for the B tile
+    static_assert((WGM * WGN == 4 || WGM * WGN == 8) && TM >= 1 && TN >= 1 && NA >= 1 && BN % RPP == 0, "4 or 8 waves");
     __shared__ __attribute__((aligned(16))) unsigned short As[2][BM * LDH];      // planes h, l'
     __shared__ __attribute__((aligned(16))) unsigned short Bs[2][BN * LDH];
 
@@ -611,21 +618,21 @@ __global__ __launch_bounds__(256, 2) void gemm_rowk(AG ag, const float *__restri
     if (!ag.tile_active(m0)) return;     // block-uniform (padding tiles of the group-sorted layouts)
     const int M = ag.rows, K = ag.K();
     const int trow = tid >> 3, tk4 = (tid & 7) * 4;
-    const int wo = (((tk4 >> 3) ^ swz(trow)) << 3) + (tk4 & 4);      // swizzled k offset of this thread's stores (rows trow + 32 i)
+    const int wo = (((tk4 >> 3) ^ swz(trow)) << 3) + (tk4 & 4);      // swizzled k offset of this thread's stores (rows trow + RPP i: same swizzle)
 
-    // A rows owned by this thread: r = trow + 32*i
+    // A rows owned by this thread: r = trow + RPP*i
     long aoff[NA];
     int ayx[NA];
     bool arow_ok[NA];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-        int r = m0 + trow + 32 * i;
+        int r = m0 + trow + RPP * i;
         arow_ok[i] = r < M;
         int iy0, ix0;
         ag.row(arow_ok[i] ? r : 0, aoff[i], iy0, ix0);
         ayx[i] = (iy0 << 16) | (ix0 & 0xFFFF);
     }
-    static_assert(NB == 1 || NB == 2 || NB == 4, "B tile of 32, 64 or 128 rows");
+    static_assert(NB == 1 || NB == 2 || NB == 4, "B tile of 1, 2 or 4 passes");
     const float *brow0 = Bt + (long)(ag.bn(n0, m0) + trow) * ldb + tk4;
 
     float4 ra[NA];
@@ -646,9 +653,9 @@ __global__ __launch_bounds__(256, 2) void gemm_rowk(AG ag, const float *__restri
         /* named scalars, not an array: an array here is "promoted" to LDS by the compiler */             \
         const int bko = ag.bk((kt_) * BK, m0);                                                             \
         rb0 = *reinterpret_cast<const float4 *>(brow0 + bko);                                              \
-        if (NB > 1) rb1 = *reinterpret_cast<const float4 *>(brow0 + (long)32 * ldb + bko);                 \
-        if (NB > 2) rb2 = *reinterpret_cast<const float4 *>(brow0 + (long)64 * ldb + bko);                 \
-        if (NB > 2) rb3 = *reinterpret_cast<const float4 *>(brow0 + (long)96 * ldb + bko);                 \
+        if (NB > 1) rb1 = *reinterpret_cast<const float4 *>(brow0 + (long)RPP * ldb + bko);                \
+        if (NB > 2) rb2 = *reinterpret_cast<const float4 *>(brow0 + (long)2 * RPP * ldb + bko);            \
+        if (NB > 2) rb3 = *reinterpret_cast<const float4 *>(brow0 + (long)3 * RPP * ldb + bko);            \
     }
 #define GRL_STORE_PLANES(S_, o_, v4_)                                                                      \
     {                                                                                                      \
@@ -664,12 +671,12 @@ __global__ __launch_bounds__(256, 2) void gemm_rowk(AG ag, const float *__restri
             float4 t4 = ra[i];                                                                             \
             t4.x = v ? t4.x : 0.f; t4.y = v ? t4.y : 0.f; t4.z = v ? t4.z : 0.f; t4.w = v ? t4.w : 0.f;    \
             if (AG::kRelu) { t4.x = fmaxf(t4.x, 0.f); t4.y = fmaxf(t4.y, 0.f); t4.z = fmaxf(t4.z, 0.f); t4.w = fmaxf(t4.w, 0.f); } \
-            GRL_STORE_PLANES(As, (trow + 32 * i) * LDH + wo, t4)                                           \
+            GRL_STORE_PLANES(As, (trow + RPP * i) * LDH + wo, t4)                                          \
         }                                                                                                  \
         GRL_STORE_PLANES(Bs, trow * LDH + wo, rb0)                                                         \
-        if (NB > 1) GRL_STORE_PLANES(Bs, (trow + 32) * LDH + wo, rb1)                                      \
-        if (NB > 2) GRL_STORE_PLANES(Bs, (trow + 64) * LDH + wo, rb2)                                      \
-        if (NB > 2) GRL_STORE_PLANES(Bs, (trow + 96) * LDH + wo, rb3)                                      \
+        if (NB > 1) GRL_STORE_PLANES(Bs, (trow + RPP) * LDH + wo, rb1)                                     \
+        if (NB > 2) GRL_STORE_PLANES(Bs, (trow + 2 * RPP) * LDH + wo, rb2)                                 \
+        if (NB > 2) GRL_STORE_PLANES(Bs, (trow + 3 * RPP) * LDH + wo, rb3)                                 \
     }
 
     f32x4 acc[TM][TN], acl[TM][TN];
@@ -701,18 +708,34 @@ __global__ __launch_bounds__(256, 2) void gemm_rowk(AG ag, const float *__restri
         }
         GRL_SCHED_FENCE
         {   // one K = 32 step per tile
-            f16x8 bf[TN][2];
+            if constexpr (TM < TN) {      // keep the smaller operand's fragments live, stream the other one (fewer registers)
+                f16x8 af[TM][2];
 #pragma unroll
-            for (int b = 0; b < TN; ++b)
+                for (int a = 0; a < TM; ++a)
 #pragma unroll
-                for (int p = 0; p < 2; ++p) bf[b][p] = *reinterpret_cast<const f16x8 *>(&Bs[p][bro + b * 16 * LDH]);
+                    for (int p = 0; p < 2; ++p) af[a][p] = *reinterpret_cast<const f16x8 *>(&As[p][aro + a * 16 * LDH]);
 #pragma unroll
-            for (int a = 0; a < TM; ++a) {
-                f16x8 af[2];
+                for (int b = 0; b < TN; ++b) {
+                    f16x8 bf[2];
 #pragma unroll
-                for (int p = 0; p < 2; ++p) af[p] = *reinterpret_cast<const f16x8 *>(&As[p][aro + a * 16 * LDH]);
+                    for (int p = 0; p < 2; ++p) bf[p] = *reinterpret_cast<const f16x8 *>(&Bs[p][bro + b * 16 * LDH]);
 #pragma unroll
-                for (int b = 0; b < TN; ++b) mfma_x3(acc[a][b], acl[a][b], af, bf[b]);
+                    for (int a = 0; a < TM; ++a) mfma_x3(acc[a][b], acl[a][b], af[a], bf);
+                }
+            } else {
+                f16x8 bf[TN][2];
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) bf[b][p] = *reinterpret_cast<const f16x8 *>(&Bs[p][bro + b * 16 * LDH]);
+#pragma unroll
+                for (int a = 0; a < TM; ++a) {
+                    f16x8 af[2];
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) af[p] = *reinterpret_cast<const f16x8 *>(&As[p][aro + a * 16 * LDH]);
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) mfma_x3(acc[a][b], acl[a][b], af, bf[b]);
+                }
             }
         }
         GRL_SCHED_FENCE
@@ -803,12 +826,12 @@ __global__ __launch_bounds__(256, 2) void gemm_rowk(AG ag, const float *__restri
 // tile [column][m].  Column 4*c4 + j sits in LDS row j*(BM/4) + c4, which spreads a store's lanes over the banks; the
 // epilogue undoes the permutation.
 template <int BM, int BN, int WGM, int WGN, class AG, int XCD_ORDER = 1>
-__global__ __launch_bounds__(256, 2) void gemm_tn(AG ag, const float *__restrict__ dY, int J, int mc, float *__restrict__ slab) {
-    constexpr int BK = 32, LDH = kLdh;
+__global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void gemm_tn(AG ag, const float *__restrict__ dY, int J, int mc, float *__restrict__ slab) {
+    constexpr int BK = 32, LDH = kLdh, NT = 64 * WGM * WGN;
     constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 16, TN = WN / 16;
     constexpr int A4 = BM / 4, B4 = BN / 4;           // float4 per reduction row
-    constexpr int NA = BK * A4 / 256, NB = BK * B4 / 256;
-    static_assert(WGM * WGN == 4 && NA >= 1 && NB >= 1 && NA <= 4 && NB <= 4, "tile size");
+    constexpr int NA = BK * A4 / NT, NB = BK * B4 / NT;
+    static_assert((WGM * WGN == 4 || WGM * WGN == 8) && NA >= 1 && NB >= 1 && NA <= 4 && NB <= 4 && (NA != 3) && (NB != 3), "tile size");
     __shared__ __attribute__((aligned(16))) unsigned short As[2][BM * LDH];
     __shared__ __attribute__((aligned(16))) unsigned short Bs[2][BN * LDH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -953,18 +976,34 @@ __global__ __launch_bounds__(256, 2) void gemm_tn(AG ag, const float *__restrict
             GRL_LOAD_IDX(mt + 2 * BK)
             GRL_SCHED_FENCE
             {
-                f16x8 bf[TN][2];
+                if constexpr (TM < TN) {      // keep the smaller operand's fragments live, stream the other one (fewer registers)
+                    f16x8 af[TM][2];
 #pragma unroll
-                for (int b = 0; b < TN; ++b)
+                    for (int a = 0; a < TM; ++a)
 #pragma unroll
-                    for (int p = 0; p < 2; ++p) bf[b][p] = *reinterpret_cast<const f16x8 *>(&Bs[p][bro + b * 16 * LDH]);
+                        for (int p = 0; p < 2; ++p) af[a][p] = *reinterpret_cast<const f16x8 *>(&As[p][aro + a * 16 * LDH]);
 #pragma unroll
-                for (int a = 0; a < TM; ++a) {
-                    f16x8 af[2];
+                    for (int b = 0; b < TN; ++b) {
+                        f16x8 bf[2];
 #pragma unroll
-                    for (int p = 0; p < 2; ++p) af[p] = *reinterpret_cast<const f16x8 *>(&As[p][aro + a * 16 * LDH]);
+                        for (int p = 0; p < 2; ++p) bf[p] = *reinterpret_cast<const f16x8 *>(&Bs[p][bro + b * 16 * LDH]);
 #pragma unroll
-                    for (int b = 0; b < TN; ++b) mfma_x3(acc[a][b], acl[a][b], af, bf[b]);
+                        for (int a = 0; a < TM; ++a) mfma_x3(acc[a][b], acl[a][b], af[a], bf);
+                    }
+                } else {
+                    f16x8 bf[TN][2];
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+#pragma unroll
+                        for (int p = 0; p < 2; ++p) bf[b][p] = *reinterpret_cast<const f16x8 *>(&Bs[p][bro + b * 16 * LDH]);
+#pragma unroll
+                    for (int a = 0; a < TM; ++a) {
+                        f16x8 af[2];
+#pragma unroll
+                        for (int p = 0; p < 2; ++p) af[p] = *reinterpret_cast<const f16x8 *>(&As[p][aro + a * 16 * LDH]);
+#pragma unroll
+                        for (int b = 0; b < TN; ++b) mfma_x3(acc[a][b], acl[a][b], af, bf[b]);
+                    }
                 }
             }
             GRL_SCHED_FENCE

@@ -419,6 +419,106 @@ __global__ __launch_bounds__(256, 2) void rowk_adirect(const float *__restrict__
 #undef LOADT
 }
 
+
+// ---------------------------------------------------------------------------- eight waves per workgroup
+// Same 128 x 128 tile and the same bytes per FLOP from L2, but 512 threads: wave tiles of 32 x 64 (64 accumulator registers instead
+// of 128), so four waves fit a SIMD where the 4-wave form fits two -- more waves to cover the waits of the load path.
+template <int BM, int BN, int WGM, int WGN, int MINB>
+__global__ __launch_bounds__(512, MINB) void rowk_w8(const float *__restrict__ A, const float *__restrict__ Bt, float *__restrict__ C, int M, int N, int K) {
+    constexpr int BK = 32, LDH = 32;
+    constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 16, TN = WN / 16, NA = BM / 64, NB = BN / 64;
+    static_assert(WGM * WGN == 8, "8 waves");
+    __shared__ __attribute__((aligned(16))) unsigned short As[2][BM * LDH];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[2][BN * LDH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave - wm * WGN;
+    int bx_ = blockIdx.x, by_ = blockIdx.y;
+    {
+        const int nx = gridDim.x, L = by_ * nx + bx_, g = L / (8 * nx);
+        if ((g + 1) * 8 <= (int)gridDim.y) {
+            const int l = L - g * 8 * nx;
+            by_ = g * 8 + (l & 7);
+            bx_ = l >> 3;
+        }
+    }
+    const int m0 = by_ * BM, n0 = bx_ * BN;
+    const int trow = tid >> 3, tk4 = (tid & 7) * 4;      // 64 rows per pass
+    const int wo = (((tk4 >> 3) ^ swz(trow)) << 3) + (tk4 & 4);
+    const float *arow = A + (long)(m0 + trow) * K + tk4;
+    const float *brow = Bt + (long)(n0 + trow) * K + tk4;
+    const int l16 = lane & 15, kg = lane >> 4;
+    float4 ra[NA], rb[NB];
+#define LOADT(kt_)                                                                                                                     \
+    {                                                                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const float4 *>(arow + (long)64 * i * K + (kt_) * BK); \
+        _Pragma("unroll") for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const float4 *>(brow + (long)64 * i * K + (kt_) * BK); \
+    }
+    LOADT(0)
+    f32x4 acc[TM][TN], acl[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[a][b][r] = acl[a][b][r] = 0.f;
+    const int rofs = (kg ^ swz(l16)) << 3;
+    const int aro = (wm * WM + l16) * LDH + rofs, bro = (wn * WN + l16) * LDH + rofs;
+    const int nk = K / BK;
+    for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int o = (trow + 64 * i) * LDH + wo;      // swz(row + 64) == swz(row)
+            uint2 h, l;
+            hsplit4(ra[i], h, l);
+            *reinterpret_cast<uint2 *>(&As[0][o]) = h;
+            *reinterpret_cast<uint2 *>(&As[1][o]) = l;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int o = (trow + 64 * i) * LDH + wo;
+            uint2 h, l;
+            hsplit4(rb[i], h, l);
+            *reinterpret_cast<uint2 *>(&Bs[0][o]) = h;
+            *reinterpret_cast<uint2 *>(&Bs[1][o]) = l;
+        }
+        __syncthreads();
+        LOADT(kt + 1 < nk ? kt + 1 : kt)
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            f16x8 bf[TN][2];
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) bf[b][p] = *reinterpret_cast<const f16x8 *>(&Bs[p][bro + b * 16 * LDH]);
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                f16x8 af[2];
+#pragma unroll
+                for (int p = 0; p < 2; ++p) af[p] = *reinterpret_cast<const f16x8 *>(&As[p][aro + a * 16 * LDH]);
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    acl[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[1], bf[b][0], acl[a][b], 0, 0, 0);
+                    acl[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[0], bf[b][1], acl[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[0], bf[b][0], acc[a][b], 0, 0, 0);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int row = m0 + wm * WM + a * 16 + 4 * kg + r;
+                int col = n0 + wn * WN + b * 16 + l16;
+                if (row < M && col < N) C[(long)row * N + col] = __builtin_fmaf(acl[a][b][r], 1.f / 2048.f, acc[a][b][r]);
+            }
+#undef LOADT
+}
+
 static double err_vs_double(const std::vector<float> &A, const std::vector<float> &B, const std::vector<float> &C, int M, int N, int K, double *rms_out) {
     double worst = 0., ss = 0.;
     long cnt = 0;
@@ -504,6 +604,19 @@ static void variant_x(const char *name, const float *A, const float *B, const un
     fflush(stdout);
 }
 
+template <int BM, int BN, int WGM, int WGN, int MINB>
+static void variant_w8(const char *name, const float *A, const float *B, float *C, int M, int N, int K, const std::vector<float> &hA,
+                       const std::vector<float> &hB, std::vector<float> &hC) {
+    const double flops = 2.0 * M * N * K;
+    dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM);
+    (void)hipMemset(C, 0, (size_t)M * N * 4);
+    float ms = time_ms([&] { hipLaunchKernelGGL((rowk_w8<BM, BN, WGM, WGN, MINB>), grid, dim3(512), 0, 0, A, B, C, M, N, K); }, 20);
+    (void)hipMemcpy(hC.data(), C, hC.size() * 4, hipMemcpyDeviceToHost);
+    double rms, w = err_vs_double(hA, hB, hC, M, N, K, &rms);
+    printf("M %6d N %4d K %4d  %-44s %8.3f ms %7.1f TF   err/sum|ab| worst %.3g rms %.3g\n", M, N, K, name, ms, flops / ms / 1e9, w, rms);
+    fflush(stdout);
+}
+
 template <int PIPE>
 static void variant_db(const char *name, const float *A, const float *B, float *C, int M, int N, int K, const std::vector<float> &hA,
                        const std::vector<float> &hB, std::vector<float> &hC) {
@@ -536,6 +649,9 @@ static void run(int M, int N, int K, float amag, float bmag) {
     variant<1>("three fp16 products, scaled low plane", A, B, Bp, C, M, N, K, hA, hB, hC);
     variant<3>("three fp16 products, weights pre-split", A, B, Bp, C, M, N, K, hA, hB, hC);
     variant<7>("three fp16 products, XCD-aware tile order", A, B, Bp, C, M, N, K, hA, hB, hC);
+    variant_w8<128, 128, 4, 2, 2>("8 waves, 128x128, 32x64 wave tiles, 2 WG/CU", A, B, C, M, N, K, hA, hB, hC);
+    variant_w8<128, 128, 2, 4, 2>("8 waves, 128x128, 64x32 wave tiles, 2 WG/CU", A, B, C, M, N, K, hA, hB, hC);
+    variant_w8<256, 128, 4, 2, 1>("8 waves, 256x128, 64x64 wave tiles, 1 WG/CU", A, B, C, M, N, K, hA, hB, hC);
     variant<6>("(speed only) no global loads in the loop", A, B, Bp, C, M, N, K, hA, hB, hC);
     variant_x<0>("three fp16, 256x64 tile, both through LDS", A, B, Bp, C, M, N, K, hA, hB, hC);
     variant_x<1>("three fp16, 256x64 tile, A direct to registers", A, B, Bp, C, M, N, K, hA, hB, hC);
