@@ -50,6 +50,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+// Scheduling fences around gemm_rowk's MFMA block keep the next tile's global loads ahead of it (FENCE = true: +4-7 % on the dense
+// forward / data-gradient instances); the weight-gradient loop (gemm_tn) and the dense1 patch forward are faster when the compiler
+// interleaves staging, fragment reads and MFMAs itself (patch weight gradient: -22 %), measured per family on one box.
 #ifndef GRL_SCHED_FENCE
 #define GRL_SCHED_FENCE __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -588,7 +591,7 @@ __device__ __forceinline__ int swz(int row) { return (0x78 >> (((row >> 2) & 3) 
 // loop waits on its loads and barriers more than on the matrix pipe, and more resident waves cover those waits (+4-18 % on the
 // dense1 shapes, most on short K: tools/ubench/gemm_f16x3.hip).  The second launch bound is waves per SIMD (HIP-Clang): two
 // workgroups per CU either way, i.e. a 256- or 128-register budget.
-template <int BM, int BN, int WGM, int WGN, class AG, class Epi, bool XCD_ORDER = true>
+template <int BM, int BN, int WGM, int WGN, class AG, class Epi, bool XCD_ORDER = true, bool FENCE = true>
 __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void gemm_rowk(AG ag, const float *__restrict__ Bt, int ldb, int N, Epi epi) {
     constexpr int BK = 32, LDH = kLdh, NT = 64 * WGM * WGN, RPP = NT / 8;          // RPP: tile rows staged per pass (8 threads per row)
     constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 16, TN = WN / 16;       // 16x16 MFMA tiles per wave
@@ -706,7 +709,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void gemm_rowk(AG ag
             const int ktl = ktn < nk ? ktn : kt;
             GRL_LOAD_TILE(ktl)
         }
-        GRL_SCHED_FENCE
+        if constexpr (FENCE) { GRL_SCHED_FENCE }
         {   // one K = 32 step per tile
             if constexpr (TM < TN) {      // keep the smaller operand's fragments live, stream the other one (fewer registers)
                 f16x8 af[TM][2];
@@ -738,7 +741,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void gemm_rowk(AG ag
                 }
             }
         }
-        GRL_SCHED_FENCE
+        if constexpr (FENCE) { GRL_SCHED_FENCE }
         __syncthreads();
         kt = ktn;
     }
@@ -974,7 +977,6 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void gemm_tn(AG ag, 
             __syncthreads();
             GRL_LOAD_TILE()                  // rows mt + BK .. (row 0, masked, past the end of the range)
             GRL_LOAD_IDX(mt + 2 * BK)
-            GRL_SCHED_FENCE
             {
                 if constexpr (TM < TN) {      // keep the smaller operand's fragments live, stream the other one (fewer registers)
                     f16x8 af[TM][2];
@@ -1006,7 +1008,6 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void gemm_tn(AG ag, 
                     }
                 }
             }
-            GRL_SCHED_FENCE
             __syncthreads();
         }
     }
