@@ -4,11 +4,30 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
+#include <set>
 #include <cmath>
 
 #include "common.h"
 
 static thread_local std::string g_create_error;
+static std::mutex g_live_mutex;
+static std::set<const grl_handle *> g_live_handles;
+
+namespace grl {
+bool grl_handle_alive(const grl_handle *h) {
+    std::lock_guard<std::mutex> lk(g_live_mutex);
+    return g_live_handles.count(h) != 0;
+}
+void grl_sync_for_destroy(grl_handle *h) {
+    if (grl_handle_alive(h)) {
+        hipSetDevice(h->cfg.device_id);
+        if (h->stream) hipStreamSynchronize(h->stream);
+    } else {
+        hipDeviceSynchronize();
+    }
+}
+}  // namespace grl
 
 namespace grl {
 
@@ -219,6 +238,10 @@ int grl_create(const grl_config *cfg, grl_handle **out) {
     if ((e = hipSetDevice(cfg->device_id)) != hipSuccess) return fail(nullptr, GRL_E_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
 
     grl_handle *h = new grl_handle();
+    {
+        std::lock_guard<std::mutex> lk(g_live_mutex);
+        g_live_handles.insert(h);
+    }
     h->cfg = *cfg;
     h->E = cfg->num_envs;
     h->step_in_flight = false;
@@ -269,6 +292,10 @@ int grl_destroy(grl_handle *h) {
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
     if (h->stream) hipStreamDestroy(h->stream);
+    {
+        std::lock_guard<std::mutex> lk(g_live_mutex);
+        g_live_handles.erase(h);
+    }
     delete h;
     return GRL_OK;
 }

@@ -96,6 +96,12 @@ struct grl_handle {
 
 namespace grl {
 int fail(grl_handle *h, int code, const std::string &msg);
+// Is h a handle grl_create returned and grl_destroy has not freed?  A net keeps a pointer to the handle it was created on; a
+// host binding's garbage collector may finalise the two in either order, so the grl_*net_destroy functions ask before they
+// touch the handle's device id and stream.
+bool grl_handle_alive(const grl_handle *h);
+// binds the handle's device and drains its stream if the handle is alive, else drains the current device
+void grl_sync_for_destroy(grl_handle *h);
 // bracket the dominant kernel of a step with an event pair when profiling is on
 void prof_begin(grl_handle *h);
 void prof_end(grl_handle *h);

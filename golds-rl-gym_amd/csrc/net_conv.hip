@@ -652,6 +652,8 @@ int grl_net_config_default(int32_t kind, grl_net_config *cfg) {
     return GRL_OK;
 }
 
+static int range_flag_init(grl_net *n);
+
 int grl_net_create(grl_handle *h, const grl_net_config *cfg, grl_net **out) {
     if (!h || !cfg || !out) return GRL_E_INVALID;
     *out = nullptr;
@@ -719,6 +721,7 @@ int grl_net_create(grl_handle *h, const grl_net_config *cfg, grl_net **out) {
                                             (int)EXP2_LDS_BYTES) != hipSuccess)
         rc = nfail(n, GRL_E_HIP, "hipFuncSetAttribute(expand_conv2_kernel)");
     if (rc == GRL_OK) rc = ensure_tmp_obs(n, h->E);
+    if (rc == GRL_OK) rc = range_flag_init(n);
     if (rc != GRL_OK) {
         fail(h, rc, "grl_net_create: " + n->err);
         grl_net_destroy(n);
@@ -731,13 +734,13 @@ int grl_net_create(grl_handle *h, const grl_net_config *cfg, grl_net **out) {
 
 int grl_net_destroy(grl_net *n) {
     if (!n) return GRL_OK;
-    hipSetDevice(n->h->cfg.device_id);
-    hipStreamSynchronize(n->h->stream);
+    const bool alive = grl_handle_alive(n->h);      // the handle may have been destroyed first (finaliser order of a host binding)
+    grl_sync_for_destroy(n->h);
     if (n->comm) {
         ncclCommDestroy((ncclComm_t)n->comm);
         (void)hipGetLastError();   // RCCL teardown may leave a stale HIP error on this thread
     }
-    use_lane(n, 0);
+    if (alive) use_lane(n, 0);      // restores the handle's stream
     for (int k = 1; k < GRL_MAX_LANES; ++k) {
         if (n->lane_stream[k]) { hipStreamSynchronize(n->lane_stream[k]); hipStreamDestroy(n->lane_stream[k]); }
         if (n->ev_join[k]) hipEventDestroy(n->ev_join[k]);
@@ -795,8 +798,32 @@ int grl_net_set_optimizer_state(grl_net *n, const float *m_host, const float *v_
     return GRL_OK;
 }
 
+// After a synchronisation point: did any GEMM output of the work just finished leave the fp16 range (net_gemm.h: g_gemm_range_flag)?
+// The results of that work are then wrong (inf / NaN operands, which ReLU turns into zeros), so the call fails instead of returning them.
+static int *g_range_flag_dev = nullptr;      // one device per process (one process per GPU); never freed
+static int range_flag_init(grl_net *n) {
+    if (g_range_flag_dev) return GRL_OK;
+    int *p = nullptr;
+    NET_HIP(n, hipMalloc((void **)&p, sizeof(int)));
+    NET_HIP(n, hipMemset(p, 0, sizeof(int)));
+    NET_HIP(n, hipMemcpyToSymbol(HIP_SYMBOL(grl::g_gemm_range_flag), &p, sizeof(p)));
+    (void)hipGetLastError();      // the symbol lookup may probe other ordinals and leave a stale error on this thread
+    g_range_flag_dev = p;
+    return GRL_OK;
+}
+static int range_check(grl_net *n, const char *where) {
+    int flag = 0;
+    NET_HIP(n, hipMemcpy(&flag, g_range_flag_dev, sizeof(int), hipMemcpyDeviceToHost));
+    if (!flag) return GRL_OK;
+    NET_HIP(n, hipMemset(g_range_flag_dev, 0, sizeof(int)));
+    NET_HIP(n, hipDeviceSynchronize());
+    return nfail(n, GRL_E_RANGE, std::string(where) + ": an activation or gradient exceeded 65504, the range of the fp16 matrix-pipe GEMMs "
+                                                      "(include/goldsrl_net.h, Arithmetic); the results of this call are not valid");
+}
+
 static int download_heads(grl_net *n, int B, float *mu_host, float *sigma_host, float *vs_host) {
     NET_HIP(n, hipStreamSynchronize(n->h->stream));
+    if (int rc = range_check(n, "grl_net_predict")) return rc;
     if (mu_host) NET_HIP(n, hipMemcpy(mu_host, n->mu, (size_t)B * n->ho.A * 4, hipMemcpyDeviceToHost));
     if (sigma_host) NET_HIP(n, hipMemcpy(sigma_host, n->sigma, (size_t)B * n->ho.A * 4, hipMemcpyDeviceToHost));
     if (vs_host) NET_HIP(n, hipMemcpy(vs_host, n->vs, (size_t)B * 4, hipMemcpyDeviceToHost));

@@ -519,8 +519,7 @@ int grl_fieldnet_create(grl_handle *h, const grl_fieldnet_config *cfg, grl_field
 
 int grl_fieldnet_destroy(grl_fieldnet *n) {
     if (!n) return GRL_OK;
-    hipSetDevice(n->h->cfg.device_id);
-    hipStreamSynchronize(n->h->stream);
+    grl_sync_for_destroy(n->h);      // the handle may have been destroyed first (finaliser order of a host binding)
     for (void *p : n->allocs) hipFree(p);
     delete n;
     return GRL_OK;

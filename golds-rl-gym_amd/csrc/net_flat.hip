@@ -396,8 +396,7 @@ int grl_fnet_create(grl_handle *h, const grl_fnet_config *cfg, grl_fnet **out) {
 
 int grl_fnet_destroy(grl_fnet *n) {
     if (!n) return GRL_OK;
-    hipSetDevice(n->h->cfg.device_id);
-    hipStreamSynchronize(n->h->stream);
+    grl_sync_for_destroy(n->h);      // the handle may have been destroyed first (finaliser order of a host binding)
     if (n->ro_graph) (void)hipGraphExecDestroy(n->ro_graph);
     if (n->comm) {
         ncclCommDestroy((ncclComm_t)n->comm);

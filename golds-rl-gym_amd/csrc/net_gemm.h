@@ -45,6 +45,13 @@ struct epi_row_bits : std::false_type {};
 template <class E>
 struct epi_row_bits<E, std::void_t<decltype(E::kRowBits)>> : std::bool_constant<E::kRowBits> {};
 
+// an epilogue whose elem_aux is ADDED to the accumulator (bias, per-env part, shared pre-activation) says so: the range guard
+// checks what is stored, not the bare product (kAddAux)
+template <class E, class = void>
+struct epi_add_aux : std::false_type {};
+template <class E>
+struct epi_add_aux<E, std::void_t<decltype(E::kAddAux)>> : std::bool_constant<E::kAddAux> {};
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -372,7 +379,7 @@ enum { ACT_NONE = 0, ACT_RELU = 1 };
 
 
 struct EpiBiasAct {
-    static constexpr bool kColSum = false;   // C[r][c] = act(v + bias[c])
+    static constexpr bool kColSum = false, kAddAux = true;   // C[r][c] = act(v + bias[c])
     float *C;
     int ldc;
     const float *bias;
@@ -387,7 +394,7 @@ struct EpiBiasAct {
 };
 
 struct EpiBiasDual {
-    static constexpr bool kColSum = false;   // C[r][c] = v + bias[c] and C2[r][c] = relu(v + bias[c]): pre-activation and activation in one pass
+    static constexpr bool kColSum = false, kAddAux = true;   // C[r][c] = v + bias[c] and C2[r][c] = relu(v + bias[c]): pre-activation and activation in one pass
     float *C, *C2;
     int ldc;
     const float *bias;
@@ -405,7 +412,7 @@ struct EpiBiasDual {
 // a2_a - a2sh = relu(z + v) - relu(z), plus one word of 64 channel sign bits of relu(z + v) per slot row.  The slot index is
 // resolved once per output row (row_aux_n: the workgroup's 64 columns are one canonical output), not per element.
 struct EpiConv2Corr {
-    static constexpr bool kColSum = false;
+    static constexpr bool kColSum = false, kAddAux = true;
     static constexpr bool kRowBits = true;
     float *d2;
     unsigned long long *m2;
@@ -425,7 +432,7 @@ struct EpiConv2Corr {
 };
 
 struct EpiPatchFwd {
-    static constexpr bool kColSum = false;   // sorted row -> sample m: out[m][c] = relu(v + ysh[env(m)][c]) (ysh = per-env part incl. bias)
+    static constexpr bool kColSum = false, kAddAux = true;   // sorted row -> sample m: out[m][c] = relu(v + ysh[env(m)][c]) (ysh = per-env part incl. bias)
     float *out;
     const float *ysh;
     const int *perm;
@@ -581,6 +588,11 @@ __device__ __forceinline__ void mfma_x3(f32x4 &acc, f32x4 &acl, const f16x8 (&a)
 // reads one ds_read_b128 per plane with the 16 lanes of every service group on 16 distinct 4-bank slots, and the staging
 // stores of gemm_rowk (8 lanes per row, 8 bytes each) cover whole rows: both conflict free (checked by enumeration).
 constexpr int kLdh = 32;
+// Range guard of the fp16 operand form: every gemm_rowk output is a later GEMM's operand, so a tile whose accumulators leave the
+// fp16 range (|v| > 65 504: the next split would turn it into inf, and ReLU's max would swallow the NaN that follows) raises this
+// sticky flag; the host reads it at its next synchronisation point and fails the call with GRL_E_RANGE (net_conv.hip: range_check).
+__device__ int *g_gemm_range_flag;      // -> one hipMalloc'd word per process, set when the first net is created
+constexpr float kF16Max = 65504.f;
 // wave layouts of the two large tile shapes (WGM x WGN waves; 4 x 2 and 8 x 1: eight waves with 32 x 64 wave tiles)
 constexpr int kW128M = 4, kW128N = 2, kW256M = 8, kW256N = 1;
 __device__ __forceinline__ int swz(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }
@@ -757,6 +769,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void gemm_rowk(AG ag
     const int erow = m0 + wm * WM + 4 * kg, ecol = n0 + wn * WN + l16;
     int rax[TM][4];
     float eax[TM][TN][4];
+    bool out_of_range = false;
     // the loads are unconditional on clamped coordinates: a per-element predicate would wrap every load in its own
     // exec-mask block with a wait behind it
 #pragma unroll
@@ -781,7 +794,11 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void gemm_rowk(AG ag
             for (int r = 0; r < 4; ++r) {
                 const int row = erow + a * 16 + r, col = ecol + b * 16;
                 if (row < M && col < N) epi.store(row, col, acc[a][b][r], rax[a][r], eax[a][b][r]);
+                // range guard: what this tile hands to the next GEMM must be a finite fp16-range number (padding rows hold zeros)
+                const float gv = epi_add_aux<Epi>::value ? acc[a][b][r] + eax[a][b][r] : acc[a][b][r];
+                out_of_range |= !(fabsf(gv) <= kF16Max);
             }
+    if (out_of_range) atomicOr(g_gemm_range_flag, 1);
     if constexpr (Epi::kColSum) {      // column sums of the stored values over this wave's rows, in a fixed order
 #pragma unroll
         for (int b = 0; b < TN; ++b) {

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libgoldsrl.so")
 ENV_SWARM, ENV_SOLOW, ENV_TRADE, ENV_TICKER = 0, 1, 2, 3
 F_RESEED_EACH_RESET, F_RESET_FROM_SNAPSHOT, F_INJECT_NOISE, F_SWARM_FAST_MATH, F_SWARM_NO_OBSERVE, F_SOLOW_SS_RESET = 1, 2, 4, 8, 16, 32
 
-OK, E_INVALID, E_NO_DEVICE, E_HIP, E_SIZE, E_ACTION_RANGE, E_STATE, E_COMM = 0, -1, -2, -3, -4, -5, -6, -7
+OK, E_INVALID, E_NO_DEVICE, E_HIP, E_SIZE, E_ACTION_RANGE, E_STATE, E_COMM, E_RANGE = 0, -1, -2, -3, -4, -5, -6, -7, -8
 
 # enum grl_field
 FLD = dict(

@@ -42,6 +42,7 @@ extern "C" {
 #define GRL_E_ACTION_RANGE (-5) /* TradeAR1: action outside Box(-1,1) (reference: AssertionError, fed_env.py:301) */
 #define GRL_E_STATE (-6)        /* call order violated (e.g. grl_wait without a step in flight) */
 #define GRL_E_COMM (-7)         /* RCCL failure */
+#define GRL_E_RANGE (-8)        /* conv policy: an activation / gradient left the fp16 range of the matrix-pipe GEMMs (goldsrl_net.h) */
 
 /* ---- environment kinds (gym ids: fed_gym/__init__.py:3-33) -------------------------- */
 #define GRL_ENV_SWARM 0 /* Swarm-v0 / Swarm-eval-v0   (envs/multiagent.py) */

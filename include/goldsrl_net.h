@@ -13,9 +13,9 @@
  * Arithmetic: float32 in, float32 out, float32 accumulation, as the reference's TF graph.  conv2, conv3 and the dense layers run
  * on the fp16 matrix pipe with every fp32 operand split into two fp16 terms (22-23 significand bits; csrc/net_gemm.h), which
  * measures closer to a float64 evaluation than a plain float32 one.  Range contract of that form: activations and weights
- * below 65 504 in magnitude (larger ones become inf and show as a non-finite loss / global_norm in the statistics; nothing is
- * clamped); gradient passes pick an exact power-of-two loss scale per call, so advantages / targets of any float32 magnitude
- * are fine.  GRL_NET_LOSS_SCALE=off in the environment disables that scale (diagnostic only).
+ * below 65 504 in magnitude.  Nothing is clamped: every GEMM checks its output tile, and the first call that synchronises
+ * after a violation (predict, train_*, apply_grads) returns GRL_E_RANGE instead of results computed from inf operands.
+ * Gradient passes pick an exact power-of-two loss scale per call, so advantages / targets of any float32 magnitude are fine.  GRL_NET_LOSS_SCALE=off in the environment disables that scale (diagnostic only).
  */
 #ifndef GOLDSRL_NET_H
 #define GOLDSRL_NET_H

@@ -170,6 +170,39 @@ def test_without_the_loss_scale_small_head_gradients_are_lost(monkeypatch):
     assert out["on"] == 0.0 and out["off"] > 1e-3, out
 
 
+def test_operands_beyond_the_fp16_range_fail_the_call():
+    """Range contract of the fp16 matrix-pipe GEMMs (include/goldsrl_net.h): an activation above 65 504 cannot be represented in the
+    operand planes (it would become inf, and ReLU's max would turn the NaNs that follow into plausible zeros), so every GEMM checks
+    its output tile and the call that synchronises next fails with GRL_E_RANGE instead of returning such results."""
+    from goldsrl import _ffi
+    E = 2
+    eng, net, p, states, obs = _setup(E)
+    flat = net.get_params().copy()
+    q = NN.unflatten_params(flat.astype(np.float64))
+    q["conv2_b"] = q["conv2_b"] + 3.0e5      # relu(conv2) = 3e5 everywhere: conv3's output (the next GEMM operand) is far outside
+    net.set_params(NN.flatten_params(q).astype(np.float32))
+    with pytest.raises(_ffi.GrlError) as ei:
+        net.predict()
+    assert ei.value.code == _ffi.E_RANGE and "65504" in str(ei.value)
+    act, adv, y = _train_inputs(E)
+    with pytest.raises(_ffi.GrlError) as ei:
+        net.train_obs(*obs, act, adv, y, lr=0.0, apply_update=False)
+    assert ei.value.code == _ffi.E_RANGE
+    # the flag is cleared by the failing call: the same net inside the range works again, and is unchanged
+    net.set_params(flat)
+    assert np.isfinite(net.predict()["vs"]).all()
+    assert np.isfinite(net.train_obs(*obs, act, adv, y, lr=0.0, apply_update=False)["global_norm"])
+    # large but representable activations are fine (no false positives near the limit: relu(conv2) ~ 2e3)
+    q["conv2_b"] = q["conv2_b"] - 3.0e5 + 2.0e3
+    net.set_params(NN.flatten_params(q).astype(np.float32))
+    out = net.predict()
+    mu, sigma, vs, c = NN.conv_forward(q, states, 1000.0, keep=True)
+    ref = c["d1"]
+    got = net.read_activation("d1", ref.shape).astype(np.float64)
+    assert np.abs(ref).max() > 1e3 and np.abs(got - ref).max() / np.abs(ref).max() < 2e-5
+    np.testing.assert_allclose(out["mu"], mu, atol=1e-4)
+
+
 @pytest.mark.parametrize("A", [1, 3, 4])
 def test_num_actions_is_a_parameter_of_the_heads(A):
     """ConvSingleAgentPolicyNetwork takes conf['num_actions'] (policy_v_network.py:10,40-43; the reference's own shape test
