@@ -519,6 +519,109 @@ __global__ __launch_bounds__(512, MINB) void rowk_w8(const float *__restrict__ A
 #undef LOADT
 }
 
+
+// ---------------------------------------------------------------------------- eight waves + two LDS buffers, one barrier per K-tile
+template <int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(512, 4) void rowk_w8db(const float *__restrict__ A, const float *__restrict__ Bt, float *__restrict__ C, int M, int N, int K) {
+    constexpr int BK = 32, LDH = 32;
+    constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 16, TN = WN / 16, NA = BM / 64, NB = BN / 64;
+    constexpr int ABUF = 2 * BM * LDH, BBUF = 2 * BN * LDH;
+    __shared__ __attribute__((aligned(16))) unsigned short As[2 * ABUF];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[2 * BBUF];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave - wm * WGN;
+    int bx_ = blockIdx.x, by_ = blockIdx.y;
+    {
+        const int nx = gridDim.x, L = by_ * nx + bx_, g = L / (8 * nx);
+        if ((g + 1) * 8 <= (int)gridDim.y) {
+            const int l = L - g * 8 * nx;
+            by_ = g * 8 + (l & 7);
+            bx_ = l >> 3;
+        }
+    }
+    const int m0 = by_ * BM, n0 = bx_ * BN;
+    const int trow = tid >> 3, tk4 = (tid & 7) * 4;
+    const int wo = (((tk4 >> 3) ^ swz(trow)) << 3) + (tk4 & 4);
+    const float *arow = A + (long)(m0 + trow) * K + tk4;
+    const float *brow = Bt + (long)(n0 + trow) * K + tk4;
+    const int l16 = lane & 15, kg = lane >> 4;
+    float4 ra[NA], rb[NB];
+#define LOADT(kt_)                                                                                                                     \
+    {                                                                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const float4 *>(arow + (long)64 * i * K + (kt_) * BK); \
+        _Pragma("unroll") for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const float4 *>(brow + (long)64 * i * K + (kt_) * BK); \
+    }
+#define STORET(buf_)                                                                                               \
+    {                                                                                                              \
+        _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                           \
+            const int o = (buf_) * ABUF + (trow + 64 * i) * LDH + wo;                                              \
+            uint2 h, l;                                                                                            \
+            hsplit4(ra[i], h, l);                                                                                  \
+            *reinterpret_cast<uint2 *>(&As[o]) = h;                                                                \
+            *reinterpret_cast<uint2 *>(&As[o + BM * LDH]) = l;                                                     \
+        }                                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                           \
+            const int o = (buf_) * BBUF + (trow + 64 * i) * LDH + wo;                                              \
+            uint2 h, l;                                                                                            \
+            hsplit4(rb[i], h, l);                                                                                  \
+            *reinterpret_cast<uint2 *>(&Bs[o]) = h;                                                                \
+            *reinterpret_cast<uint2 *>(&Bs[o + BN * LDH]) = l;                                                     \
+        }                                                                                                          \
+    }
+    f32x4 acc[TM][TN], acl[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[a][b][r] = acl[a][b][r] = 0.f;
+    const int rofs = (kg ^ swz(l16)) << 3;
+    const int aro = (wm * WM + l16) * LDH + rofs, bro = (wn * WN + l16) * LDH + rofs;
+    const int nk = K / BK;
+    LOADT(0)
+    STORET(0)
+    LOADT(nk > 1 ? 1 : 0)
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const unsigned short *Ac = As + cur * ABUF, *Bc = Bs + cur * BBUF;
+        if (kt + 1 < nk) STORET(cur ^ 1)      // tile kt+1 (registers) into the other buffer; nobody reads it before the barrier below
+        LOADT(kt + 2 < nk ? kt + 2 : kt)
+        {
+            f16x8 af[TM][2];
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) af[a][p] = *reinterpret_cast<const f16x8 *>(&Ac[p * BM * LDH + aro + a * 16 * LDH]);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                f16x8 bf[2];
+#pragma unroll
+                for (int p = 0; p < 2; ++p) bf[p] = *reinterpret_cast<const f16x8 *>(&Bc[p * BN * LDH + bro + b * 16 * LDH]);
+#pragma unroll
+                for (int a = 0; a < TM; ++a) {
+                    acl[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[a][1], bf[0], acl[a][b], 0, 0, 0);
+                    acl[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[a][0], bf[1], acl[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[a][0], bf[0], acc[a][b], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int row = m0 + wm * WM + a * 16 + 4 * kg + r;
+                int col = n0 + wn * WN + b * 16 + l16;
+                if (row < M && col < N) C[(long)row * N + col] = __builtin_fmaf(acl[a][b][r], 1.f / 2048.f, acc[a][b][r]);
+            }
+#undef LOADT
+#undef STORET
+}
+
 static double err_vs_double(const std::vector<float> &A, const std::vector<float> &B, const std::vector<float> &C, int M, int N, int K, double *rms_out) {
     double worst = 0., ss = 0.;
     long cnt = 0;
@@ -617,6 +720,18 @@ static void variant_w8(const char *name, const float *A, const float *B, float *
     fflush(stdout);
 }
 
+static void variant_w8db(const char *name, const float *A, const float *B, float *C, int M, int N, int K, const std::vector<float> &hA,
+                         const std::vector<float> &hB, std::vector<float> &hC) {
+    const double flops = 2.0 * M * N * K;
+    dim3 grid((N + 127) / 128, (M + 127) / 128);
+    (void)hipMemset(C, 0, (size_t)M * N * 4);
+    float ms = time_ms([&] { hipLaunchKernelGGL((rowk_w8db<128, 128, 4, 2>), grid, dim3(512), 0, 0, A, B, C, M, N, K); }, 20);
+    (void)hipMemcpy(hC.data(), C, hC.size() * 4, hipMemcpyDeviceToHost);
+    double rms, w = err_vs_double(hA, hB, hC, M, N, K, &rms);
+    printf("M %6d N %4d K %4d  %-44s %8.3f ms %7.1f TF   err/sum|ab| worst %.3g rms %.3g\n", M, N, K, name, ms, flops / ms / 1e9, w, rms);
+    fflush(stdout);
+}
+
 template <int PIPE>
 static void variant_db(const char *name, const float *A, const float *B, float *C, int M, int N, int K, const std::vector<float> &hA,
                        const std::vector<float> &hB, std::vector<float> &hC) {
@@ -649,8 +764,9 @@ static void run(int M, int N, int K, float amag, float bmag) {
     variant<1>("three fp16 products, scaled low plane", A, B, Bp, C, M, N, K, hA, hB, hC);
     variant<3>("three fp16 products, weights pre-split", A, B, Bp, C, M, N, K, hA, hB, hC);
     variant<7>("three fp16 products, XCD-aware tile order", A, B, Bp, C, M, N, K, hA, hB, hC);
-    variant_w8<128, 128, 4, 2, 2>("8 waves, 128x128, 32x64 wave tiles, 2 WG/CU", A, B, C, M, N, K, hA, hB, hC);
-    variant_w8<128, 128, 2, 4, 2>("8 waves, 128x128, 64x32 wave tiles, 2 WG/CU", A, B, C, M, N, K, hA, hB, hC);
+    variant_w8<128, 128, 4, 2, 4>("8 waves, 128x128, 32x64 wave tiles, 2 WG/CU", A, B, C, M, N, K, hA, hB, hC);
+    variant_w8db("8 waves, 128x128, two LDS buffers, one barrier", A, B, C, M, N, K, hA, hB, hC);
+    variant_w8<128, 128, 2, 4, 4>("8 waves, 128x128, 64x32 wave tiles, 2 WG/CU", A, B, C, M, N, K, hA, hB, hC);
     variant_w8<256, 128, 4, 2, 1>("8 waves, 256x128, 64x64 wave tiles, 1 WG/CU", A, B, C, M, N, K, hA, hB, hC);
     variant<6>("(speed only) no global loads in the loop", A, B, Bp, C, M, N, K, hA, hB, hC);
     variant_x<0>("three fp16, 256x64 tile, both through LDS", A, B, Bp, C, M, N, K, hA, hB, hC);
