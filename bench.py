@@ -404,6 +404,7 @@ def main():
                                                 MFMA_F16_PEAK_TFLOPS, F16_PRODUCTS_PER_FP32, MFMA_F16_PEAK_TFLOPS / 6, F16_PRODUCTS_PER_FP32,
                                                 MFMA_F32_PEAK_TFLOPS),
                                "executed_f16_tflops": ach * F16_PRODUCTS_PER_FP32,
+                               "frac_of_round1_six_product_peak": ach / (MFMA_F16_PEAK_TFLOPS / 6.0),
                                "vs_fp32_mfma_peak": ach / MFMA_F32_PEAK_TFLOPS,
                                "traffic": gtraffic, "launches": launches, "gemm_ms_total": ms,
                                "gemm_share_of_step": (ms * 1e-3) / gemm_step_s if gemm_step_s else None,
