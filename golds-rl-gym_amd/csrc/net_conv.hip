@@ -394,40 +394,68 @@ __global__ __launch_bounds__(256) void conv1_sparse_shared_kernel(const uint8_t 
 
 // ------------------------------------------------------------------------------------------ heads
 // mu = tanh(p1 Wmu + b), sigma = sigmoid(p1 Wsg + b), vs = -scale*softplus(v2 Wv3 + b)
-// (policy_v_network.py:40-59).  One wave per sample row.
+// (policy_v_network.py:40-59).
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
 
+// kHeadRows rows per wave: each lane keeps its 8 + 4 weight rows in registers and has 3 * kHeadRows 16-byte loads in flight (one
+// row per wave with 4-byte loads left the kernel at 2.4 TB/s: latency bound).
+constexpr int kHeadRows = 4;
 template <int A>
 __global__ __launch_bounds__(256) void heads_forward_kernel(const float *__restrict__ p1, const float *__restrict__ v2,
                                                             const float *__restrict__ params, HeadOff o, int n, float scale,
                                                             float *__restrict__ mu, float *__restrict__ sigma, float *__restrict__ vs) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row >= n) return;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * kHeadRows, lane = threadIdx.x & 63;
+    if (row0 >= n) return;
     const float *muw = params + o.muw, *sgw = params + o.sgw, *v3w = params + o.v3w;
-    float m[A], s[A], zv = 0;
+    // this lane's inputs: p1 columns 4 lane .. + 3 and 256 + 4 lane .. + 3, v2 columns 4 lane .. + 3
+    float wm[8][A], ws[8][A];
 #pragma unroll
-    for (int a = 0; a < A; ++a) { m[a] = 0; s[a] = 0; }
-    for (int k = lane; k < 512; k += 64) {
-        float x = p1[(size_t)row * 512 + k];
+    for (int j = 0; j < 8; ++j) {
+        const int k = (j >> 2) * 256 + 4 * lane + (j & 3);
 #pragma unroll
-        for (int a = 0; a < A; ++a) { m[a] += x * muw[k * A + a]; s[a] += x * sgw[k * A + a]; }
+        for (int a = 0; a < A; ++a) { wm[j][a] = muw[k * A + a]; ws[j][a] = sgw[k * A + a]; }
     }
-    for (int k = lane; k < 256; k += 64) zv += v2[(size_t)row * 256 + k] * v3w[k];
+    const float4 wv = reinterpret_cast<const float4 *>(v3w)[lane];
+    float4 x0[kHeadRows], x1[kHeadRows], xv[kHeadRows];
 #pragma unroll
-    for (int a = 0; a < A; ++a) { m[a] = wave_sum(m[a]); s[a] = wave_sum(s[a]); }
-    zv = wave_sum(zv);
-    if (lane == 0) {
+    for (int r = 0; r < kHeadRows; ++r) {
+        const size_t row = (size_t)min(row0 + r, n - 1);      // clamped: the tail rows are loaded twice and not stored
+        x0[r] = reinterpret_cast<const float4 *>(p1 + row * 512)[lane];
+        x1[r] = reinterpret_cast<const float4 *>(p1 + row * 512 + 256)[lane];
+        xv[r] = reinterpret_cast<const float4 *>(v2 + row * 256)[lane];
+    }
+    // lane 16 r + i keeps output i of row r (i < A: mu, < 2A: sigma, = 2A: value), so the transcendental functions of the four rows
+    // run once per wave side by side instead of 2A + 1 of them in sequence on lane 0 of every row
+    float mine = 0.f;
+#pragma unroll
+    for (int r = 0; r < kHeadRows; ++r) {
+        const float x[8] = {x0[r].x, x0[r].y, x0[r].z, x0[r].w, x1[r].x, x1[r].y, x1[r].z, x1[r].w};
 #pragma unroll
         for (int a = 0; a < A; ++a) {
-            mu[(size_t)row * A + a] = tanhf(m[a] + params[o.mub + a]);
-            sigma[(size_t)row * A + a] = 1.0f / (1.0f + expf(-(s[a] + params[o.sgb + a])));
+            float m = 0.f, sg = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { m += x[j] * wm[j][a]; sg += x[j] * ws[j][a]; }
+            m = wave_sum(m);
+            sg = wave_sum(sg);
+            if (lane == 16 * r + a) mine = m;
+            if (lane == 16 * r + A + a) mine = sg;
         }
-        zv += params[o.v3b];
-        float sp = zv > 20.f ? zv : log1pf(expf(zv));
+        const float zv = wave_sum(xv[r].x * wv.x + xv[r].y * wv.y + xv[r].z * wv.z + xv[r].w * wv.w);
+        if (lane == 16 * r + 2 * A) mine = zv;
+    }
+    const int r = lane >> 4, i = lane & 15, row = row0 + r;
+    if (row >= n || i > 2 * A) return;
+    if (i < A) {
+        mu[(size_t)row * A + i] = tanhf(mine + params[o.mub + i]);
+    } else if (i < 2 * A) {
+        sigma[(size_t)row * A + (i - A)] = 1.0f / (1.0f + expf(-(mine + params[o.sgb + (i - A)])));
+    } else {
+        const float zv = mine + params[o.v3b];
+        const float sp = zv > 20.f ? zv : log1pf(expf(zv));
         vs[row] = -scale * sp;
     }
 }
@@ -554,7 +582,7 @@ static int forward_chunk(grl_net *net, const uint8_t *lb, const uint8_t *ab, con
     dense(net->d2, 256, PT + net->ho.v1w, P + net->ho.v1b, 512, net->v1);
     dense(net->v1, 512, PT + net->ho.v2w, P + net->ho.v2b, 256, net->v2);
     }
-    GRL_HEADS_DISPATCH(net->ho.A, hipLaunchKernelGGL(heads_forward_kernel<kA>, dim3((n + 3) / 4), dim3(256), 0, st, net->p1, net->v2, P, net->ho, n,
+    GRL_HEADS_DISPATCH(net->ho.A, hipLaunchKernelGGL(heads_forward_kernel<kA>, dim3((n + 4 * kHeadRows - 1) / (4 * kHeadRows)), dim3(256), 0, st, net->p1, net->v2, P, net->ho, n,
                                                       net->cfg.scale, mu, sigma, vs));
     NET_HIP(net, hipGetLastError());
     return GRL_OK;
