@@ -28,7 +28,8 @@
 // gradients, which are scaled by a power of two chosen per update (net_train.inc: loss_scale_kernel) and unscaled
 // exactly when the flat gradient is complete.
 //
-// 256 threads = 4 waves, BK = 32, register prefetch of the next K-tile so the global loads fly under the MFMAs.  LDS
+// 256 or 512 threads (4 or 8 waves, chosen per instance: see gemm_rowk), BK = 32, register prefetch of the next K-tile so the
+// global loads fly under the MFMAs; an operand above the fp16 range is caught by the range guard in gemm_rowk's epilogue.  LDS
 // holds two fp16 planes per operand in 64-byte rows with an XOR swizzle of the 16-byte chunks (kLdh, swz below): an
 // MFMA fragment (8 consecutive k of one row) is one conflict-free ds_read_b128 per plane.
 #pragma once
