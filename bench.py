@@ -387,7 +387,7 @@ def main():
         if gemm is not None:
             launches, ms, flops = gemm
             ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-            gtraffic = None      # HBM bytes per GEMM launch from the committed PMC passes (same 40 960-sample chunks)
+            gtraffic = None      # HBM bytes per GEMM launch from the committed PMC passes (same 81 920-sample chunks)
             gpath = os.path.join(ROOT, "profiles", GEMM_TRAFFIC_FILE)
             if os.path.exists(gpath):
                 with open(gpath) as f:

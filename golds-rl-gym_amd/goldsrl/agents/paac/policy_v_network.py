@@ -27,7 +27,7 @@ class ConvSingleAgentPolicyNetwork(object):
             raise Exception('Norm type not recognized')
         self.net = None
 
-    def bind(self, engine, gamma=0.99, seed=3, chunk=40960):
+    def bind(self, engine, gamma=0.99, seed=3, chunk=81920):
         clip = self.clip_norm if self.clip_norm_type == 'global' else 0.0
         self.net = _ffi_net.ConvNet(engine, max_chunk_samples=min(chunk, engine.E * 10), scale=self.scale,
                                     entropy_beta=self.entropy_beta, clip_norm=clip, gamma=gamma, num_actions=self.num_actions)

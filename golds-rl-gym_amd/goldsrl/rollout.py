@@ -19,7 +19,7 @@ class _GradientExchange(object):
 
 
 class ConvPolicyRollout(_GradientExchange):
-    def __init__(self, eng, T, train=True, lr=1e-4, reward_layout=0, seed=3, chunk=40960, **net_kw):
+    def __init__(self, eng, T, train=True, lr=1e-4, reward_layout=0, seed=3, chunk=81920, **net_kw):
         self.eng, self.T, self.train, self.lr, self.reward_layout = eng, T, train, lr, reward_layout
         chunk = min(chunk, eng.E * 10)
         self.net = _ffi_net.ConvNet(eng, max_chunk_samples=chunk, **net_kw)

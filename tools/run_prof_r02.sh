@@ -1,5 +1,6 @@
 # Round-2 evidence, rocprofv3 on the GPU box (kernel-trace/stats and every PMC group in its own pass):
-#   part A  one full PAAC update at 4 096 envs, single stream: per-kernel stats, FETCH_SIZE, WRITE_SIZE, SQ counters
+#   part A  one full PAAC update at 8 192 envs (ONE 81 920-sample chunk per step, the timed configuration's chunk), single stream:
+#           per-kernel stats, FETCH_SIZE, WRITE_SIZE, SQ counters
 #   part B  the TIMED configuration (32 768 envs, four streams): kernel trace (busy union, concurrency), then serialised PMC
 #           passes (SQ busy / MFMA busy, FETCH_SIZE, WRITE_SIZE) whose totals say what the 0.7 s are spent on
 #   part C  env-only (random policy): the Swarm step kernel's duration and HBM traffic
@@ -11,7 +12,7 @@ mkdir -p gpurun_out
 P=gpurun_out/r02
 note() { echo "$(date +%T) $1" >> gpurun_out/r02_prof.progress; }
 if [ "$PART" = "A" ]; then
-  ARGS="bench.py --envs 4096 --steps 2 --warmup 0 --no-cpu-baseline --no-extras --single-stream"
+  ARGS="bench.py --envs 8192 --steps 2 --warmup 0 --no-cpu-baseline --no-extras --single-stream"
   note "A stats";  rocprofv3 --kernel-trace --stats --output-format csv -d ${P}_A_stats -- python3 $ARGS > ${P}_A_stats.log 2>&1
   note "A fetch";  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d ${P}_A_fetch -- python3 $ARGS > ${P}_A_fetch.log 2>&1
   note "A write";  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d ${P}_A_write -- python3 $ARGS > ${P}_A_write.log 2>&1

@@ -33,7 +33,7 @@ if part in ("A", "C"):
     rows = list(csv.DictReader(open(one(P + "_stats/*/*_kernel_stats.csv"))))
     fetch, write = counters("fetch"), counters("write")
     avg = lambda d, k, c: (sum(d[k][c]) / len(d[k][c])) if k in d and c in d[k] else float("nan")
-    out = "gpurun_out/r02_%s_summary.csv" % ("full_update_e4096" if part == "A" else "envonly")
+    out = "gpurun_out/r02_%s_summary.csv" % ("full_update_e8192" if part == "A" else "envonly")
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
     with open(out, "w") as f:
         f.write("kernel,calls,total_ms,avg_us,pct,FETCH_SIZE_avg_KB,WRITE_SIZE_avg_KB\n")
@@ -53,12 +53,12 @@ if part in ("A", "C"):
                    "hbm_bytes_per_launch": g_bytes / max(g_calls, 1), "hbm_bytes_total": g_bytes, "updates_in_this_pass": updates,
                    "kernel_ms_per_update": tot / 1e6 / updates, "gemm_share_of_kernel_time": g_ns / tot, "non_gemm_share_of_kernel_time": non / tot,
                    "correction": "FETCH_SIZE x2 (gfx950), WRITE_SIZE as is, unit KB; per-kernel averages weighted by calls",
-                   "source": "tools/run_prof_r02.sh A: bench.py --envs 4096 --steps 2 --warmup 0 --single-stream (3 updates: 2 timed + the HIP-event pass)"},
+                   "source": "tools/run_prof_r02.sh A: bench.py --envs 8192 --steps 2 --warmup 0 --single-stream (3 updates: 2 timed + the HIP-event pass)"},
                   open("gpurun_out/r02_gemm_traffic.json", "w"), indent=1)
         print(open("gpurun_out/r02_gemm_traffic.json").read())
         sq = counters("sq")
         names = ["SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_ANY", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_LDS_BANK_CONFLICT", "SQ_BUSY_CYCLES"]
-        with open("gpurun_out/r02_sq_counters_e4096.csv", "w") as f:
+        with open("gpurun_out/r02_sq_counters_e8192.csv", "w") as f:
             f.write("kernel,launches," + ",".join(names) + "\n")
             for k in sorted(sq, key=lambda k: -sum(sq[k].get("SQ_WAVE_CYCLES", [0]))):
                 n = len(sq[k].get("SQ_WAVE_CYCLES", [1]))
