@@ -144,6 +144,11 @@ struct grl_net : NetLane {
     int last_n;                // samples in the last chunk (for read_activation)
     void *comm;                // ncclComm_t (RCCL) for the per-rollout gradient all-reduce, or nullptr
     int comm_world, comm_rank;
+    hipEvent_t ar_ev0, ar_ev1; // bracket the all-reduce on the handle's stream (grl_net_comm_info)
+    int ar_pending;
+    long ar_calls;
+    double ar_ms_total;
+    float ar_ms_last;
     // Rollout-resident activations: the rollout's forward pass writes its activations of every (step, chunk) into one
     // T*B-sample buffer (what 288 GB of HBM is for) and the gradient step reads them back instead of recomputing the
     // forward pass.  Exact: parameters do not change between the two (paac.py:302-387).  keep_version tracks that;
@@ -828,22 +833,29 @@ int grl_net_set_optimizer_state(grl_net *n, const float *m_host, const float *v_
 
 // After a synchronisation point: did any GEMM output of the work just finished leave the fp16 range (net_gemm.h: g_gemm_range_flag)?
 // The results of that work are then wrong (inf / NaN operands, which ReLU turns into zeros), so the call fails instead of returning them.
-static int *g_range_flag_dev = nullptr;      // one device per process (one process per GPU); never freed
+// One word per DEVICE (the __device__ pointer g_gemm_range_flag has one instance per device; a process that creates nets on two
+// devices gets two words); nets on the same device share it.  Never freed.
+constexpr int kMaxDevices = 64;
+static int *g_range_flag_dev[kMaxDevices] = {};
 static int range_flag_init(grl_net *n) {
-    if (g_range_flag_dev) return GRL_OK;
+    const int dev = n->h->cfg.device_id;
+    if (dev < 0 || dev >= kMaxDevices) return nfail(n, GRL_E_INVALID, "device ordinal beyond 63");
+    if (g_range_flag_dev[dev]) return GRL_OK;
+    NET_HIP(n, hipSetDevice(dev));
     int *p = nullptr;
     NET_HIP(n, hipMalloc((void **)&p, sizeof(int)));
     NET_HIP(n, hipMemset(p, 0, sizeof(int)));
-    NET_HIP(n, hipMemcpyToSymbol(HIP_SYMBOL(grl::g_gemm_range_flag), &p, sizeof(p)));
+    NET_HIP(n, hipMemcpyToSymbol(HIP_SYMBOL(grl::g_gemm_range_flag), &p, sizeof(p)));      // this device's instance of the symbol
     (void)hipGetLastError();      // the symbol lookup may probe other ordinals and leave a stale error on this thread
-    g_range_flag_dev = p;
+    g_range_flag_dev[dev] = p;
     return GRL_OK;
 }
+static int *range_flag_ptr(grl_net *n) { return g_range_flag_dev[n->h->cfg.device_id]; }
 static int range_check(grl_net *n, const char *where) {
     int flag = 0;
-    NET_HIP(n, hipMemcpy(&flag, g_range_flag_dev, sizeof(int), hipMemcpyDeviceToHost));
+    NET_HIP(n, hipMemcpy(&flag, range_flag_ptr(n), sizeof(int), hipMemcpyDeviceToHost));
     if (!flag) return GRL_OK;
-    NET_HIP(n, hipMemset(g_range_flag_dev, 0, sizeof(int)));
+    NET_HIP(n, hipMemset(range_flag_ptr(n), 0, sizeof(int)));
     NET_HIP(n, hipDeviceSynchronize());
     return nfail(n, GRL_E_RANGE, std::string(where) + ": an activation or gradient exceeded 65504, the range of the fp16 matrix-pipe GEMMs "
                                                       "(include/goldsrl_net.h, Arithmetic); the results of this call are not valid");

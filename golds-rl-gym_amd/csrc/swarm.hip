@@ -62,6 +62,22 @@ __device__ __forceinline__ void x_update(double &x, double &y, double vx, double
     if (y <= 0) y = 0;
 }
 
+// x_update for the agents when the action row is FLOAT32 -- what the worker reads from the learner's shared c_float array
+// (quirk Q7; emulator_runner.py:126, paac.py:269).  numpy keeps the row's dtype through `v_action[:, 0] += WIND_SPEED`
+// (multiagent.py:33-36) and through `dt * v` (a Python float times a float32 array is a float32 product with dt rounded to
+// float32, multiagent.py:72); only the sum with the float64 noise is float64.  Pinned by tests/golden/swarm_runner.npz
+// (SwarmRunner._run itself): evaluating the action term in float64 differs by ~6e-9 per step, which the chaotic dynamics amplify.
+__device__ __forceinline__ void x_update_f32v(double &x, double &y, float vx, float vy, double nx, double ny) {
+    if (y <= 0) {
+        y = 0;
+        vx = 0;
+        if (vy <= 0) vy = 0;
+    }
+    x = x + ((double)(0.05f * vx) + NOISE * nx);
+    y = y + ((double)(0.05f * vy) + NOISE * ny);
+    if (y <= 0) y = 0;
+}
+
 template <bool FAST>
 __device__ __forceinline__ void pair_term(double sx, double sy, double xj, double yj, double &t0, double &t1) {
     double dx = sx - xj, dy = sy - yj;
@@ -115,15 +131,17 @@ __device__ __forceinline__ void locust_velocity(const double2 *src, double xj, d
 }
 
 // One SwarmEnv._step for the 4 envs of the block, state in LDS (agents) / registers (own locust).
-// Agent lanes (tid < 40) carry (actx, acty) = action BEFORE wind and (anx, any) raw noise.
+// Agent lanes (tid < 40) carry (actx, acty) = action BEFORE wind and (anx, any) raw noise; act32: the action came from a
+// float32 row and its wind / dt arithmetic is float32 (x_update_f32v).
 // On return L.p holds the new positions of all 90 points, L.rew[el] the reward; ends on a barrier.
 template <bool FAST>
 __device__ __forceinline__ void block_step(SwarmLds &L, int tid, int el, int j, double &xj, double &yj, double actx,
-                                           double acty, double anx, double any, double pnx, double pny) {
+                                           double acty, double anx, double any, double pnx, double pny, bool act32 = false) {
     if (tid < SWARM_EPB * N_AGENTS) {
         int ea = tid / N_AGENTS, a = tid - ea * N_AGENTS;
         double2 q = L.p[ea][N_LOCUSTS + a];
-        x_update(q.x, q.y, actx + WIND, acty, anx, any);   // wind: multiagent.py:35-36
+        if (act32) x_update_f32v(q.x, q.y, (float)actx + 1.0f, (float)acty, anx, any);
+        else x_update(q.x, q.y, actx + WIND, acty, anx, any);   // wind: multiagent.py:35-36
         L.p[ea][N_LOCUSTS + a] = q;
     }
     L.p[el][j] = make_double2(xj, yj);
@@ -225,7 +243,7 @@ __global__ __launch_bounds__(SWARM_TPB) void swarm_kernel(SwarmParams P) {
             double2 n = reinterpret_cast<const double2 *>(P.anoise)[(size_t)aenv * N_AGENTS + a];
             anx = n.x; any = n.y;
         }
-        block_step<FAST>(L, tid, el, j, xj, yj, actx, acty, anx, any, pnx, pny);
+        block_step<FAST>(L, tid, el, j, xj, yj, actx, acty, anx, any, pnx, pny, P.actions64 == nullptr);
         if (active) reinterpret_cast<double2 *>(P.x)[(size_t)env * N_LOCUSTS + j] = make_double2(xj, yj);
         if (aactive) reinterpret_cast<double2 *>(P.xa)[(size_t)aenv * N_AGENTS + a] = L.p[ea][N_LOCUSTS + a];
         if (active && j == 0) {

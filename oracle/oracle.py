@@ -73,10 +73,14 @@ def swarm_v_calculate(x, xa):
 
 def swarm_step(x, xa, action, agent_noise_row, particle_noise_row, add_wind=True):
     """SwarmEnv._step (envs/multiagent.py:30-44), batched.  Inputs are NOT modified
-    (the reference mutates in place -- quirk Q9); returns (x', xa', reward, done)."""
+    (the reference mutates in place -- quirk Q9); returns (x', xa', reward, done).
+    The action keeps its dtype, as `v_action.copy()` does: a float32 row (what the worker reads from the learner's shared
+    array, quirk Q7) gets its wind added and its `dt * v` product taken in float32 -- pinned by tests/golden/swarm_runner.npz."""
     x = np.array(x, dtype=np.float64)
     xa = np.array(xa, dtype=np.float64)
-    v_action = np.array(action, dtype=np.float64)
+    v_action = np.array(action)
+    if v_action.dtype != np.float32:
+        v_action = v_action.astype(np.float64)
     if add_wind:
         v_action[..., 0] += WIND_SPEED
     xa = swarm_x_update(xa, v_action, NOISE * np.asarray(agent_noise_row, dtype=np.float64))
@@ -165,6 +169,20 @@ def swarm_transform_actions(actions):
     m = d >= 1
     a[m] = a[m] / d[m][:, None]
     return a
+
+
+def swarm_history_window(local_states, n_hist, rnn_length):
+    """HISTORY slot of SwarmRunner._run (agents/paac/emulator_runner.py:129-145) AS IT BEHAVES, one env: local_states
+    (10,G,G,3) is the env's current STATE row, n_hist = len(self.histories[i]) after this step's append (1 after a reset or the
+    first step).  Every list entry is a view of the shared STATE row (quirk Q11), so the window is min(n, rnn) copies of the
+    CURRENT state; while n < rnn the worker pads through keras' pad_sequences with its DEFAULT dtype int32, which truncates
+    the densities toward zero (k/80 -> 0 unless all locusts share the bin; the one-hot survives) -- restated from Keras 2.0.8,
+    third party, parity unpinned at that call.  Returns (10, rnn, G, G, 3) float64, agent-major as np.swapaxes leaves it."""
+    out = np.zeros((local_states.shape[0], rnn_length) + local_states.shape[1:])
+    n = min(int(n_hist), rnn_length)
+    cur = local_states if n_hist >= rnn_length else np.trunc(local_states)
+    out[:, :n] = cur[:, None]
+    return out
 
 
 def time_limit_done(elapsed_after_step, max_episode_steps):

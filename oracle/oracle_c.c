@@ -43,11 +43,24 @@ static double pairwise(const double *a, int n) { /* numpy pairwise_sum for 8 <= 
 
 static double s_fn(double r) { return FATT * exp(-r / LATT) - exp(-r); } /* multiagent.py:65-68 */
 
-/* one SwarmEnv._step: x (80,2) xa (10,2) updated in place; action (10,2) f64; noise rows raw N(0,1) */
-static double swarm_step_one(double *x, double *xa, const double *action, const double *an, const double *pn) {
+/* x_update for the agents with the worker's FLOAT32 action row (quirk Q7): `v_action[:, 0] += 1` and `dt * v` stay float32 in
+ * numpy (multiagent.py:33-36, 72); pinned by tests/golden/swarm_runner.npz through oracle.py */
+static void x_update_f32v(double *p, float vx, float vy, double nx, double ny) {
+    if (p[1] <= 0) {
+        p[1] = 0;
+        vx = 0;
+        if (vy <= 0) vy = 0;
+    }
+    p[0] = p[0] + ((double)(0.05f * vx) + NOISE * nx);
+    p[1] = p[1] + ((double)(0.05f * vy) + NOISE * ny);
+    if (p[1] <= 0) p[1] = 0;
+}
+
+/* one SwarmEnv._step: x (80,2) xa (10,2) updated in place; action (10,2) f32 as the worker reads it; noise rows raw N(0,1) */
+static double swarm_step_one(double *x, double *xa, const float *action, const double *an, const double *pn) {
     double v[NL][2], t0[NL], t1[NL], en[NL];
     int i, j, a;
-    for (a = 0; a < NA; ++a) x_update(&xa[2 * a], action[2 * a] + WIND, action[2 * a + 1], an[2 * a], an[2 * a + 1]);
+    for (a = 0; a < NA; ++a) x_update_f32v(&xa[2 * a], action[2 * a] + 1.0f, action[2 * a + 1], an[2 * a], an[2 * a + 1]);
     for (j = 0; j < NL; ++j) { /* v_calculate, multiagent.py:88-113 */
         double xj = x[2 * j], yj = x[2 * j + 1];
         for (i = 0; i < NL; ++i) {
@@ -112,8 +125,7 @@ int oracle_swarm_step(int E, double *x, double *xa, const float *action, const d
 #pragma omp parallel for schedule(static)
 #endif
     for (int e = 0; e < E; ++e) {
-        double act[2 * NA];
-        for (int k = 0; k < 2 * NA; ++k) act[k] = (double)action[(long)e * 2 * NA + k];
+        const float *act = action + (long)e * 2 * NA;
         reward[e] = swarm_step_one(x + (long)e * 2 * NL, xa + (long)e * 2 * NA, act, an + (long)e * 2 * NA, pn + (long)e * 2 * NL);
         if (lb) swarm_observe_one(x + (long)e * 2 * NL, xa + (long)e * 2 * NA, G, lb + (long)e * 2 * NL, ab + (long)e * 2 * NA, pos + (long)e * 2 * NA);
     }

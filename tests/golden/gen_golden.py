@@ -314,9 +314,7 @@ def trade_fixture():
 
 # --------------------------------------------------------------------------- rollout math
 def returns_fixture():
-    """n-step return/advantage exactly as the learner loops write it
-    (paac/paac.py:159-172 masked+clipped flat form; :351-365 unmasked grid form),
-    A3C GAE (agents/a3c/worker.py:232-239, 284-300), rescale_reward
+    """A3C GAE (agents/a3c/worker.py:232-239, 284-300), rescale_reward
     (paac/actor_learner.py:91-97), get_lr (:115-119), sigmoid (a3c/worker.py:17-34)."""
     from fed_gym.agents.paac.actor_learner import ActorLearner
     rng = np.random.RandomState(12)
@@ -332,24 +330,9 @@ def returns_fixture():
     for t in range(T):
         for b in range(B):
             rewards[t, b] = _L().rescale_reward(raw_rewards[t, b])
-    masks = np.zeros((T, B))
-    for t in range(T):
-        masks[t] = 1.0 - dones[t].astype(np.float32)
-    # flat / masked (paac.py:167-172)
-    y_m, adv_m = np.zeros((T, B)), np.zeros((T, B))
-    est = np.copy(boot)
-    for t in reversed(range(T)):
-        est = rewards[t] + gamma * est * masks[t]
-        y_m[t] = np.copy(est)
-        adv_m[t] = est - values[t]
-    # grid / unmasked, unclipped (paac.py:360-365)
-    y_u, adv_u = np.zeros((T, B)), np.zeros((T, B))
-    est = np.copy(boot)
+    # The n-step return loops themselves (paac.py:159-172, 351-365) are NOT transcribed here: they are pinned by
+    # tests/golden/paac_loop.npz, captured from the unmodified train() loops (gen_golden_learner.py).
     rew_u = raw_rewards.astype(np.float64)
-    for t in reversed(range(T)):
-        est = rew_u[t] + gamma * est
-        y_u[t] = np.copy(est)
-        adv_u[t] = est - values[t]
     # GAE as a3c/worker.py:284-300 for one column, lambda=0.96
     lam = 0.96
     col_r, col_v = rew_u[:, 0], np.concatenate([values[:, 0].astype(np.float64), [float(boot[0])]])
@@ -368,8 +351,7 @@ def returns_fixture():
         lrs.append(o.get_lr())
     sx = np.concatenate([np.linspace(-50, 50, 101), [-745.0, 745.0, 0.0, -0.0]])
     save("returns", gamma=np.array(gamma), lam=np.array(lam), raw_rewards=raw_rewards, clipped_rewards=rewards,
-         values=values, dones=dones, boot=boot, y_masked=y_m, adv_masked=adv_m, y_unmasked=y_u,
-         adv_unmasked=adv_u, gae_deltas=deltas, gae_adv=adv_gae, gae_targets=targets,
+         values=values, dones=dones, boot=boot, gae_deltas=deltas, gae_adv=adv_gae, gae_targets=targets,
          disc_in=disc_in, disc_out=disc_out, lr_steps=lr_steps, lrs=np.array(lrs),
          sigmoid_in=sx, sigmoid_out=a3c_worker.sigmoid(sx),
          sigmoid_scalar=np.array([a3c_worker.sigmoid(float(v)) for v in (-3.0, 0.0, 2.5)]))

@@ -147,7 +147,7 @@ def test_grid_runners_drop_in_protocol_swarm():
         actions[i] = a[i]
     runners.update_environments(); runners.wait_updated()
     x = np.stack([r[0] for r in raw]); xa = np.stack([r[1] for r in raw])
-    ox, oxa, orew, _ = O.swarm_step(x, xa, a.astype(np.float64), runners.engine.get_state("SWARM_ANOISE") * 0 + np.stack(
+    ox, oxa, orew, _ = O.swarm_step(x, xa, a, runners.engine.get_state("SWARM_ANOISE") * 0 + np.stack(
         [em._eng.get_state("SWARM_ANOISE")[0] for em in emulators]), np.stack([em._eng.get_state("SWARM_PNOISE")[0] for em in emulators]))
     np.testing.assert_allclose(rewards, np.repeat(orew[:, None], 10, 1), rtol=1e-6)
     for i in range(E):

@@ -44,7 +44,7 @@ def test_swarm_step_teacher_forced_golden(golden):
     act32 = g["action"].astype(np.float32)          # the learner's shared action buffer is float32 (runners.py:9)
     eng.step(act32)
     x, xa = eng.get_state("SWARM_X"), eng.get_state("SWARM_XA")
-    ox, oxa, orew, odone = O.swarm_step(g["x"], g["xa"], act32.astype(np.float64), g["agent_noise"], g["particle_noise"])
+    ox, oxa, orew, odone = O.swarm_step(g["x"], g["xa"], act32, g["agent_noise"], g["particle_noise"])
     assert np.array_equal(xa, oxa)                  # agents: only +,* in float64 -> bit-exact
     np.testing.assert_allclose(x, ox, rtol=1e-12, atol=1e-13)
     r64 = eng.read("reward_f64")
@@ -65,7 +65,7 @@ def test_swarm_step_fast_math_within_1e12(golden):
     eng.set_state("SWARM_PNOISE", g["particle_noise"]); eng.set_state("SWARM_ANOISE", g["agent_noise"])
     act32 = g["action"].astype(np.float32)
     eng.step(act32)
-    ox, oxa, orew, _ = O.swarm_step(g["x"], g["xa"], act32.astype(np.float64), g["agent_noise"], g["particle_noise"])
+    ox, oxa, orew, _ = O.swarm_step(g["x"], g["xa"], act32, g["agent_noise"], g["particle_noise"])
     np.testing.assert_allclose(eng.get_state("SWARM_X"), ox, rtol=1e-12, atol=1e-13)
     np.testing.assert_allclose(eng.read("reward_f64"), orew, rtol=1e-11)
 
@@ -103,7 +103,7 @@ def test_swarm_trajectory_timelimit_autoreset_golden(golden):
         a32 = act.astype(np.float32)
         eng.step(a32[None])
         # oracle on the SAME float32-rounded actions: tight; reference's float64-action run: loose
-        ox, oxa, orew, _ = O.swarm_step(ox, oxa, a32[None].astype(np.float64), oa, op)
+        ox, oxa, orew, _ = O.swarm_step(ox, oxa, a32[None], oa, op)
         d = bool(eng.read("done")[0])
         assert d == bool(g["dones"][i]), i
         np.testing.assert_allclose(eng.read("reward_f64")[0], orew[0], rtol=1e-12)
@@ -153,7 +153,7 @@ def test_swarm_batch_vs_oracle_bins_exact():
     eng = swarm_engine(E, max_episode_steps=0)
     eng.set_state("SWARM_X", x); eng.set_state("SWARM_XA", xa); eng.set_state("SWARM_PNOISE", pn); eng.set_state("SWARM_ANOISE", an)
     eng.step(act)
-    ox, oxa, orew, _ = O.swarm_step(x, xa, act.astype(np.float64), an, pn)
+    ox, oxa, orew, _ = O.swarm_step(x, xa, act, an, pn)
     gx, gxa = eng.get_state("SWARM_X"), eng.get_state("SWARM_XA")
     assert np.array_equal(gxa, oxa)
     np.testing.assert_allclose(gx, ox, rtol=1e-12, atol=1e-13)
@@ -456,15 +456,25 @@ def test_trade_batch_vs_oracle_and_price_moments():
 
 # ------------------------------------------------------------------------------------------ rollout math
 def test_returns_golden(golden):
-    g = golden("returns")
+    """R2 / R3 / R4 against the arrays of the reference's own train() loops (paac_loop.npz), R5 against gae_discount."""
     eng = solow_engine(1)
+    p = golden("paac_loop")
+    E, T, U = int(p["flat_E"]), int(p["flat_T"]), int(p["flat_updates"])
+    raw = p["flat_post_rew"].reshape(U, T, E)                # the shared reward slot, before the learner's clip
+    done = p["flat_post_done"].reshape(U, T, E)
+    for u in range(U):       # masked + clipped (paac.py:140-172), adv / scale (paac.py:177)
+        y, adv = eng.returns(raw[u], p["flat_vs"].reshape(U, T, E)[u], p["flat_boot"][u], float(p["flat_gamma"]),
+                             masks=1.0 - done[u], clip=(-2.0, 2.0), scale=float(p["flat_scale"]))
+        np.testing.assert_allclose(y, p["flat_y_batch"][u], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(adv, p["flat_adv_batch"][u] / float(p["flat_scale"]), rtol=1e-5, atol=2e-6)
+    E, T, U = int(p["grid_E"]), int(p["grid_T"]), int(p["grid_updates"])
+    for u in range(U):       # unmasked, unclipped, reward columns of quirk Q4 (paac.py:331-372)
+        y, adv = eng.returns(p["grid_rewards"][u], p["grid_vs"].reshape(U, T, E * 10)[u], p["grid_boot"][u], float(p["grid_gamma"]),
+                             scale=float(p["grid_scale"]))
+        np.testing.assert_allclose(y, p["grid_y_batch"][u], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(adv, p["grid_adv_batch"][u] / float(p["grid_scale"]), rtol=1e-5, atol=1e-8)
+    g = golden("returns")
     gamma = float(g["gamma"])
-    y, adv = eng.returns(g["raw_rewards"], g["values"], g["boot"], gamma, masks=1.0 - g["dones"], clip=(-2.0, 2.0))
-    np.testing.assert_allclose(y, g["y_masked"], rtol=1e-5, atol=1e-6)
-    np.testing.assert_allclose(adv, g["adv_masked"], rtol=1e-5, atol=1e-5)
-    y, adv = eng.returns(g["raw_rewards"], g["values"], g["boot"], gamma, scale=1000.0)
-    np.testing.assert_allclose(y, g["y_unmasked"], rtol=1e-5, atol=1e-6)
-    np.testing.assert_allclose(adv, g["adv_unmasked"] / 1000.0, rtol=1e-5, atol=1e-8)
     y, adv = eng.returns(g["raw_rewards"][:, :1], g["values"][:, :1], g["boot"][:1], gamma, lam=float(g["lam"]))
     np.testing.assert_allclose(adv[:, 0], g["gae_adv"], rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(y[:, 0], g["gae_targets"], rtol=1e-5, atol=1e-5)

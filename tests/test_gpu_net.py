@@ -306,7 +306,7 @@ def test_device_rollout_matches_oracle_pieces():
     np.testing.assert_allclose(acts[0], pred["mu"].astype(np.float64) + pred["sigma"].astype(np.float64) * eps, rtol=1e-6, atol=1e-7)
     # the env stepped with the norm-clipped action: replay step 0 on the oracle
     a_env = O.swarm_transform_actions(acts[0]).reshape(E, 10, 2)
-    ox, oxa, orew, _ = O.swarm_step(x0, xa0, a_env.astype(np.float64), an, pn)
+    ox, oxa, orew, _ = O.swarm_step(x0, xa0, a_env, an, pn)
     np.testing.assert_allclose(rews[0].reshape(E, 10), np.repeat(orew[:, None], 10, 1), rtol=1e-6)
     # observations stored per step feed the same net: values[t] == predict_obs(stored obs[t])
     lb = net.read_rollout("locust_bins", (T, E, 80, 2), np.uint8); ab = net.read_rollout("agent_bins", (T, E, 10, 2), np.uint8)

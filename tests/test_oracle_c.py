@@ -20,7 +20,7 @@ def test_c_swarm_step_and_observe_match_numpy_oracle(golden):
     g = golden("swarm_step")
     a32 = g["action"].astype(np.float32)
     x, xa, r, lb, ab, pos, used = OC.swarm_step(g["x"], g["xa"], a32, g["agent_noise"], g["particle_noise"], threads=2)
-    ox, oxa, orew, _ = O.swarm_step(g["x"], g["xa"], a32.astype(np.float64), g["agent_noise"], g["particle_noise"])
+    ox, oxa, orew, _ = O.swarm_step(g["x"], g["xa"], a32, g["agent_noise"], g["particle_noise"])
     assert np.array_equal(xa, oxa)
     np.testing.assert_allclose(x, ox, rtol=1e-13, atol=1e-14)      # glibc exp vs numpy's SIMD exp: last-ulp differences
     np.testing.assert_allclose(r, orew, rtol=1e-13)
@@ -43,9 +43,15 @@ def test_c_observe_golden_bit_exact(golden):
 
 
 def test_c_returns_match_golden(golden):
+    """oracle_c.c's return loops against the arrays of the reference's own train() loops (tests/golden/paac_loop.npz)."""
     OC = _oc()
-    g = golden("returns")
-    y, adv = OC.returns(g["raw_rewards"], g["values"], g["boot"], float(g["gamma"]))
-    assert np.array_equal(y, g["y_unmasked"]) and np.array_equal(adv, g["adv_unmasked"])
-    y, adv = OC.returns(g["clipped_rewards"].astype(np.float32), g["values"], g["boot"], float(g["gamma"]), mask=1.0 - g["dones"])
-    assert np.array_equal(y, g["y_masked"]) and np.array_equal(adv, g["adv_masked"])
+    g = golden("paac_loop")
+    E, T, U = int(g["grid_E"]), int(g["grid_T"]), int(g["grid_updates"])
+    for u in range(U):       # unmasked, unclipped (paac.py:360-365)
+        y, adv = OC.returns(g["grid_rewards"][u], g["grid_vs"].reshape(U, T, E * 10)[u], g["grid_boot"][u], float(g["grid_gamma"]))
+        assert np.array_equal(y, g["grid_y_batch"][u]) and np.array_equal(adv, g["grid_adv_batch"][u])
+    E, T, U = int(g["flat_E"]), int(g["flat_T"]), int(g["flat_updates"])
+    for u in range(U):       # masked, rewards already clipped (paac.py:145,167-172)
+        y, adv = OC.returns(g["flat_rewards"][u], g["flat_vs"].reshape(U, T, E)[u], g["flat_boot"][u], float(g["flat_gamma"]),
+                            mask=g["flat_episodes_over_masks"][u])
+        assert np.array_equal(y, g["flat_y_batch"][u]) and np.array_equal(adv, g["flat_adv_batch"][u])
