@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """bench.py -- env-steps/s of the PAAC hot path on N MI355X GPUs of one node.
 
-Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 it is launched by
-torch.distributed.run, one rank per GPU.  Prints ONE JSON line on rank 0.
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 the driver's elastic launcher starts it once per
+GPU with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set.  Prints ONE JSON line on rank 0.  The host side is the standard library
+and ctypes only: the ranks meet over goldsrl.distributed's own TCP store, the gradient crosses xGMI through RCCL inside the library.
 
 A "step" is one full PAAC update of GridPAACLearner (reference paac.py:302-387) on this rank's shard
 of Swarm-v0 envs (BASELINE configs[2]: 32 768 envs per GPU, 84x84x3 observation, T=20):
@@ -20,7 +21,7 @@ scaling = weak (32 768 envs per GPU = BASELINE configs[3] at N=8); for N>1 the l
 `strong_scaling` point (32 768 envs in total, the shape BASELINE's target is quoted on).
 
 N>1 without a launcher: `python bench.py --gpus N` starts N fresh rank processes itself (before anything
-touches the GPU) and relays rank 0's line; under torch.distributed.run WORLD_SIZE must equal --gpus.
+touches the GPU) and relays rank 0's line; under a launcher WORLD_SIZE must equal --gpus.
 """
 import argparse
 import json
@@ -68,7 +69,9 @@ def parse():
     ap.add_argument("--cpu-sample-envs", type=int, default=2048)
     ap.add_argument("--no-strong", action="store_true", help="N>1: skip the strong-scaling point (32 768 envs in total)")
     ap.add_argument("--no-flat-configs", action="store_true", help="skip the Solow-4096 / TradeAR1-16 side blocks (configs 2 and 5)")
-    ap.add_argument("--exchange", default="rccl", choices=["rccl", "gloo"], help="gradient exchange to try first for N>1")
+    ap.add_argument("--exchange", default="rccl", choices=["rccl", "host"],
+                    help="gradient exchange for N>1: RCCL all-reduce inside the library (falls back together if any rank cannot "
+                         "form the communicator), or the host-store path outright")
     return ap.parse_args()
 
 
@@ -194,6 +197,27 @@ def timed(run, wait, steps):
     return time.perf_counter() - t0
 
 
+def timed_each(run, wait, steps):
+    """K updates, the clock read after each one has drained (an update ends in a stream synchronisation anyway: its statistics
+    come back to the host, paac.py:189-194).  Returns (total seconds, [seconds per update])."""
+    per, t0 = [], time.perf_counter()
+    t_prev = t0
+    for _ in range(steps):
+        run()
+        wait()
+        t = time.perf_counter()
+        per.append(t - t_prev)
+        t_prev = t
+    return t_prev - t0, per
+
+
+def spread(per_s):
+    a = sorted(per_s)
+    n = len(a)
+    med = a[n // 2] if n % 2 else 0.5 * (a[n // 2 - 1] + a[n // 2])
+    return {"median": med * 1e3, "min": a[0] * 1e3, "max": a[-1] * 1e3, "n": n}
+
+
 def flat_config_block(kind, E, T, device_id, steps=10):
     """BASELINE configs[1] (Solow-v0, 4 096 envs) / the per-GPU share of configs[4] (TradeAR1 n=16, 65 536 envs / 8 GPUs = 8 192)
     with FlatPolicyVNetwork (GRU(32) + MLP): device-resident T-step PAAC rollout (one hipGraph) + gradient step, timed here so the
@@ -254,7 +278,7 @@ def measure_swarm(args, ranks, E, T, want_roofline, label):
     for _ in range(args.warmup):
         roll.run()
     barrier()
-    elapsed = timed(roll.run, eng.wait, args.steps)
+    elapsed, per_update = timed_each(roll.run, eng.wait, args.steps)
     ranks.barrier()
     elapsed = ranks.max(elapsed)
     # env step kernel alone (roofline_env_step): in the conv rollout every chunk's step overlaps other chunks' kernels and has no
@@ -264,7 +288,20 @@ def measure_swarm(args, ranks, E, T, want_roofline, label):
     probe.run(); eng.wait()
     env_launches, env_kernel_ms = eng.profile_read()
     eng.profile_enable(False)
-    res = {"eng": eng, "roll": roll, "net": net, "exchange": exchange, "elapsed": elapsed, "E": E,
+    comm = None
+    if net is not None and world > 1:
+        # what RCCL itself reports (ncclCommCount) and the all-reduce time per rank (HIP events around the collective), gathered
+        # to rank 0; plus the cross-rank check that the replicas still hold identical parameters after the timed updates
+        info = net.comm_info()
+        mine = json.dumps({"rank": rank, "rccl_ranks": info["rccl_ranks"], "rccl_user_rank": info["rccl_user_rank"],
+                           "allreduce_calls": info["allreduce_calls"],
+                           "allreduce_ms": info["allreduce_ms_total"] / max(info["allreduce_calls"], 1)}).encode()
+        per_rank = [json.loads(x.decode()) for x in ranks.allgather_bytes(mine)]
+        comm = {"rccl_ranks": min(r["rccl_ranks"] for r in per_rank), "per_rank": per_rank,
+                "allreduce_ms": [r["allreduce_ms"] for r in per_rank],
+                "params_equal_across_ranks": bool(D.params_equal_across_ranks(net, ranks))}
+    res = {"eng": eng, "roll": roll, "net": net, "exchange": exchange, "elapsed": elapsed, "E": E, "per_update": per_update,
+           "comm": comm,
            "env_launches": env_launches, "env_kernel_ms": env_kernel_ms, "gemm": None, "gemm_step_s": None, "gemm_tags": {}}
     # GEMM roofline: one more update of the same workload with a HIP event pair around every gemm_rowk / gemm_tn launch.
     # Per-launch events need the launches serialised, so this pass runs on one stream; the timed region above alternates
@@ -334,6 +371,8 @@ def main():
         sm = measure_swarm(sargs, ranks, E // world, T, want_roofline=False, label="strong")
         extras["strong_scaling"] = {"value": E * T * sargs.steps / sm["elapsed"], "unit": "env-steps/s", "envs_total": E,
                                     "envs_per_gpu": E // world, "steps": sargs.steps, "ms_per_step": sm["elapsed"] / sargs.steps * 1e3,
+                                    "ms_per_step_spread": spread(sm["per_update"]),
+                                    "allreduce_ms": None if sm["comm"] is None else sm["comm"]["allreduce_ms"],
                                     "gradient_exchange": sm["exchange"], "scaling": "strong"}
         if sm["net"] is not None:
             sm["net"].close()
@@ -374,7 +413,8 @@ def main():
         out = {
             "metric": "env-steps/sec (whole node), 32k parallel Swarm-v0 envs, 20-step PAAC rollout",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "ms_per_step_spread": spread(m["per_update"]),
+            "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if args.policy == "conv" else "f64", "data": "synthetic",
             "config": {"workload": "Swarm-v0 84x84, %d envs per GPU, T=%d PAAC update, conv policy of train_paac_conv.py "
                                    "(BASELINE configs[2]%s)" % (E, T, "" if world == 1 else "; %d envs over %d GPUs = configs[3] at N=8" % (E * world, world)),
@@ -384,6 +424,11 @@ def main():
                        "streams": 1 if (args.single_stream or args.policy != "conv") else 4,
                        "gradient_exchange": exchange},
         }
+        if m["comm"] is not None:
+            out["rccl_ranks"] = m["comm"]["rccl_ranks"]
+            out["gradient_exchange"] = exchange
+            out["allreduce_ms"] = m["comm"]["allreduce_ms"]
+            out["comm"] = m["comm"]
         if gemm is not None:
             launches, ms, flops = gemm
             ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
@@ -406,7 +451,10 @@ def main():
                                "executed_f16_tflops": ach * F16_PRODUCTS_PER_FP32,
                                "frac_of_round1_six_product_peak": ach / (MFMA_F16_PEAK_TFLOPS / 6.0),
                                "vs_fp32_mfma_peak": ach / MFMA_F32_PEAK_TFLOPS,
-                               "traffic": gtraffic, "launches": launches, "gemm_ms_total": ms,
+                               "traffic": gtraffic,
+                               "traffic_source": "from_profile: profiles/%s (rocprofv3 PMC passes of the same 81 920-sample chunks; "
+                                                 "not collected inside this run)" % GEMM_TRAFFIC_FILE,
+                               "launches": launches, "gemm_ms_total": ms,
                                "gemm_share_of_step": (ms * 1e-3) / gemm_step_s if gemm_step_s else None,
                                "measured": "HIP event pair around every GEMM launch of ONE extra update run right after the timed "
                                            "region on a single stream (%.1f ms); the timed region itself deals chunks round-robin "

@@ -93,10 +93,10 @@ static bool field_info(grl_handle *h, int32_t f, FieldInfo &fi) {
     if (kind == GRL_ENV_TRADE) {
         size_t n = h->cfg.n_assets;
         switch (f) {
-            case GRL_FLD_TRADE_CASH: fi = {h->tr.cash, 4, 1, false}; return true;
-            case GRL_FLD_TRADE_ASSETS: fi = {h->tr.assets, 4, 1, false}; return true;
-            case GRL_FLD_TRADE_QUANTITY: fi = {h->tr.q, 4, n, true}; return true;
-            case GRL_FLD_TRADE_PRICES: fi = {h->tr.p, 4, n, true}; return true;
+            case GRL_FLD_TRADE_CASH: fi = {h->tr.cash, 8, 1, false}; return true;
+            case GRL_FLD_TRADE_ASSETS: fi = {h->tr.assets, 8, 1, false}; return true;
+            case GRL_FLD_TRADE_QUANTITY: fi = {h->tr.q, 8, n, true}; return true;
+            case GRL_FLD_TRADE_PRICES: fi = {h->tr.p, 8, n, true}; return true;
             case GRL_FLD_TRADE_NORMALS: fi = {h->tr.normals, 4, n, true}; return true;
             case GRL_FLD_NHIST: fi = {h->tr.nhist, 4, 1, false}; return true;
             default: return false;
@@ -355,19 +355,26 @@ static int copy_field(grl_handle *h, int32_t field, void *host, size_t bytes, bo
         else GRL_HIP(h, hipMemcpy(host, fi.dev, total, hipMemcpyDeviceToHost));
         return GRL_OK;
     }
-    // (E, inner) on the host <-> (inner, E) on the device; all feature-major fields are 4-byte
-    std::vector<uint32_t> tmp(E * fi.inner);
-    uint32_t *hp = (uint32_t *)host;
-    if (to_device) {
-        for (size_t e = 0; e < E; ++e)
-            for (size_t i = 0; i < fi.inner; ++i) tmp[i * E + e] = hp[e * fi.inner + i];
-        GRL_HIP(h, hipMemcpy(fi.dev, tmp.data(), total, hipMemcpyHostToDevice));
-    } else {
-        GRL_HIP(h, hipMemcpy(tmp.data(), fi.dev, total, hipMemcpyDeviceToHost));
-        for (size_t e = 0; e < E; ++e)
-            for (size_t i = 0; i < fi.inner; ++i) hp[e * fi.inner + i] = tmp[i * E + e];
+    // (E, inner) on the host <-> (inner, E) on the device; feature-major fields are 4-byte (Solow, injected normals) or 8-byte
+    // (TradeAR1 quantity / prices)
+    auto transpose = [&](auto *hp, auto &tmp) -> int {
+        if (to_device) {
+            for (size_t e = 0; e < E; ++e)
+                for (size_t i = 0; i < fi.inner; ++i) tmp[i * E + e] = hp[e * fi.inner + i];
+            GRL_HIP(h, hipMemcpy(fi.dev, tmp.data(), total, hipMemcpyHostToDevice));
+        } else {
+            GRL_HIP(h, hipMemcpy(tmp.data(), fi.dev, total, hipMemcpyDeviceToHost));
+            for (size_t e = 0; e < E; ++e)
+                for (size_t i = 0; i < fi.inner; ++i) hp[e * fi.inner + i] = tmp[i * E + e];
+        }
+        return GRL_OK;
+    };
+    if (fi.elem == 8) {
+        std::vector<uint64_t> tmp(E * fi.inner);
+        return transpose((uint64_t *)host, tmp);
     }
-    return GRL_OK;
+    std::vector<uint32_t> tmp(E * fi.inner);
+    return transpose((uint32_t *)host, tmp);
 }
 
 int grl_set_state(grl_handle *h, int32_t field, const void *host, size_t bytes) { return copy_field(h, field, (void *)host, bytes, true); }

@@ -40,12 +40,13 @@ struct SolowState {
 };
 
 struct TradeState {
-    float *cash, *assets, *q, *p;     // q,p (n,E) asset-major
+    double *cash, *assets, *q, *p;    // float64 like the reference's numpy state (the reward is a difference of logs of two
+                                      // nearly equal asset values: float32 prices would leave it at 1e-4 relative); q,p (n,E) asset-major
     float *normals;                   // (n,E) injected
     uint32_t *nstep;                  // generator counter per env
     int32_t *nhist;                   // states in the (PAAC-style) worker history list, as SolowState::nhist
     float *obs_raw, *obs;             // (E,1+2n)
-    float std_e;
+    double std_e;
 };
 
 struct TickerState {

@@ -244,7 +244,7 @@ int solow_launch_observe(grl_handle *h) {
 
 // ------------------------------------------------------------------------------------------ TradeAR1
 struct TradeParams {
-    float *cash, *assets, *q, *p;
+    double *cash, *assets, *q, *p;
     const float *normals;
     uint32_t *nstep;
     int32_t *elapsed, *episode, *nhist;
@@ -256,15 +256,18 @@ struct TradeParams {
     int32_t *done_list, *done_count, *err_flag;
     const int32_t *reset_list, *reset_count;
     int E, n, max_steps;
-    float std_e;
+    double std_e;
     uint32_t flags, env_off;
     uint64_t seed;
 };
 
 // TradeWorker.process_state as it behaves (a3c/worker.py:420-431, quirk Q10):
-// [log(cash+1e-4), log(q+1)..., log(p+1)...]
-__device__ __forceinline__ float trade_proc(int idx, float v) { return idx == 0 ? logf(v + 1e-4f) : logf(v + 1.0f); }
+// [log(cash+1e-4), log(q+1)..., log(p+1)...]; evaluated in float64 like the reference, rounded for the float32 net input
+__device__ __forceinline__ float trade_proc(int idx, double v) { return (float)(idx == 0 ? log(v + 1e-4) : log(v + 1.0)); }
 
+// The account (cash, assets, quantities, prices) is float64 on the device, as it is in the reference (numpy float64 throughout,
+// fed_env.py:300-330): the reward log(assets') - log(assets) is a difference of two nearly equal numbers -- with float32 prices
+// it carried ~1e-7 absolute = ~1e-4 relative error.  Observations handed to the net and the reward slot are float32 (runners.py:9).
 __global__ __launch_bounds__(256) void trade_step_kernel(TradeParams R) {
     const int env = blockIdx.x * blockDim.x + threadIdx.x;
     bool done = false;
@@ -272,14 +275,17 @@ __global__ __launch_bounds__(256) void trade_step_kernel(TradeParams R) {
         const int n = R.n, S = 1 + 2 * n;
         const size_t E = R.E;
         // TradeAR1Env._step (fed_env.py:300-321)
-        float cash = R.cash[env], assets_old = R.assets[env];
-        float cost = 0.f, value = 0.f;
+        double cash = R.cash[env];
+        const double assets_old = R.assets[env];
+        double cost = 0.0, value = 0.0;
         bool bad = false;
         for (int a = 0; a < n; ++a) {
-            float act = R.actions[(size_t)env * n + a];
-            bad |= !(act >= -1.0f && act <= 1.0f);                       // action_space.contains (fed_env.py:301)
-            float p = R.p[a * E + env], q = R.q[a * E + env];
-            float q_add = act > 0.f ? (act / (float)n) * cash / p : act * q;
+            const float actf = R.actions[(size_t)env * n + a];
+            bad |= !(actf >= -1.0f && actf <= 1.0f);                     // action_space.contains (fed_env.py:301)
+            const double act = (double)actf;
+            const double p = R.p[a * E + env];
+            double q = R.q[a * E + env];
+            const double q_add = act > 0.0 ? (act / (double)n) * cash / p : act * q;
             q += q_add;
             cost += q_add * p;
             value += q * p;
@@ -287,61 +293,57 @@ __global__ __launch_bounds__(256) void trade_step_kernel(TradeParams R) {
         }
         if (bad) atomicAdd(R.err_flag, 1);
         cash = cash + (-cost);
-        float assets = cash + value;
-        bool own_done = assets < 1.0f;                                   // MIN_CASH (fed_env.py:272,313)
-        R.reward[env] = (float)(log((double)assets + 1e-4) - log((double)assets_old + 1e-4));
-        int el = R.elapsed[env] + 1;
+        const double assets = cash + value;
+        const bool own_done = assets < 1.0;                              // MIN_CASH (fed_env.py:272,313)
+        R.reward[env] = (float)(log(assets + 1e-4) - log(assets_old + 1e-4));
+        const int el = R.elapsed[env] + 1;
         done = own_done || (R.max_steps > 0 && el >= R.max_steps);
         R.done[env] = done ? 1 : 0;
-        uint32_t st = R.nstep[env];
+        const uint32_t st = R.nstep[env];
         R.nstep[env] = st + 1;
         float *oraw = R.obs_raw + (size_t)env * S, *o = R.obs + (size_t)env * S;
         if (done) {   // auto-reset (emulator_runner.py:50-52) -> TradeAR1Env._reset (fed_env.py:323-330)
-            cash = 10.f;
-            R.assets[env] = 10.f;
+            cash = 10.0;
+            R.assets[env] = 10.0;
             R.elapsed[env] = 0;
             R.nhist[env] = 1;            // histories[i] = [reset state]  (emulator_runner.py:52)
             R.episode[env] = R.episode[env] + 1;
             for (int a = 0; a < n; ++a) {
-                R.q[a * E + env] = 0.f; R.p[a * E + env] = 1.f;
+                R.q[a * E + env] = 0.0; R.p[a * E + env] = 1.0;
                 oraw[1 + a] = 0.f; oraw[1 + n + a] = 1.f;
-                o[1 + a] = trade_proc(1, 0.f); o[1 + n + a] = trade_proc(1, 1.f);
+                o[1 + a] = trade_proc(1, 0.0); o[1 + n + a] = trade_proc(1, 1.0);
             }
         } else {
             R.assets[env] = assets;
             R.elapsed[env] = el;
             {
-                int nh = R.nhist[env] + 1;
+                const int nh = R.nhist[env] + 1;
                 R.nhist[env] = nh > R.rnn + 1 ? R.rnn + 1 : nh;     // list trimmed to rnn+1 (emulator_runner.py:61)
             }
             const int pairs = (n + 1) / 2;
             for (int a = 0; a < n; a += 2) {
-                double z0, z1;
+                double z[2];
                 if (R.flags & GRL_F_INJECT_NOISE) {
-                    z0 = R.normals[a * E + env];
-                    z1 = a + 1 < n ? R.normals[(a + 1) * E + env] : 0.0;
+                    z[0] = R.normals[a * E + env];
+                    z[1] = a + 1 < n ? R.normals[(a + 1) * E + env] : 0.0;
                 } else {
-                    normal_pair(rng_block(R.seed, (uint32_t)env + R.env_off, 0u, RS_TRADE_PRICE, st * pairs + (a >> 1)), z0, z1);
+                    normal_pair(rng_block(R.seed, (uint32_t)env + R.env_off, 0u, RS_TRADE_PRICE, st * pairs + (a >> 1)), z[0], z[1]);
                 }
-                // _price_transition: p**rho_p * exp(std_e * N(0,1))  (fed_env.py:296-298)
-                float p = R.p[a * E + env];
-                p = powf(p, 0.9f) * expf(R.std_e * (float)z0);
-                R.p[a * E + env] = p;
-                float q = R.q[a * E + env];
-                oraw[1 + a] = q; oraw[1 + n + a] = p;
-                o[1 + a] = trade_proc(1, q); o[1 + n + a] = trade_proc(1, p);
-                if (a + 1 < n) {
-                    float p1 = R.p[(a + 1) * E + env];
-                    p1 = powf(p1, 0.9f) * expf(R.std_e * (float)z1);
-                    R.p[(a + 1) * E + env] = p1;
-                    float q1 = R.q[(a + 1) * E + env];
-                    oraw[2 + a] = q1; oraw[2 + n + a] = p1;
-                    o[2 + a] = trade_proc(1, q1); o[2 + n + a] = trade_proc(1, p1);
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int ak = a + k;
+                    if (ak >= n) break;
+                    // _price_transition: p**rho_p * exp(std_e * N(0,1))  (fed_env.py:296-298)
+                    const double p = pow(R.p[ak * E + env], 0.9) * exp(R.std_e * z[k]);
+                    R.p[ak * E + env] = p;
+                    const double q = R.q[ak * E + env];
+                    oraw[1 + ak] = (float)q; oraw[1 + n + ak] = (float)p;
+                    o[1 + ak] = trade_proc(1, q); o[1 + n + ak] = trade_proc(1, p);
                 }
             }
         }
         R.cash[env] = cash;
-        oraw[0] = cash;
+        oraw[0] = (float)cash;
         o[0] = trade_proc(0, cash);
     }
     compact_done(done, env, R.done_list, R.done_count);
@@ -353,14 +355,14 @@ __global__ void trade_reset_kernel(TradeParams R) {
     const int env = R.reset_list[li];
     const int n = R.n, S = 1 + 2 * n;
     const size_t E = R.E;
-    R.cash[env] = 10.f; R.assets[env] = 10.f; R.elapsed[env] = 0; R.episode[env] = R.episode[env] + 1;
+    R.cash[env] = 10.0; R.assets[env] = 10.0; R.elapsed[env] = 0; R.episode[env] = R.episode[env] + 1;
     R.nhist[env] = 0;     // explicit reset: the worker's list starts empty (emulator_runner.py:23)
     float *oraw = R.obs_raw + (size_t)env * S, *o = R.obs + (size_t)env * S;
-    oraw[0] = 10.f; o[0] = trade_proc(0, 10.f);
+    oraw[0] = 10.f; o[0] = trade_proc(0, 10.0);
     for (int a = 0; a < n; ++a) {
-        R.q[a * E + env] = 0.f; R.p[a * E + env] = 1.f;
+        R.q[a * E + env] = 0.0; R.p[a * E + env] = 1.0;
         oraw[1 + a] = 0.f; oraw[1 + n + a] = 1.f;
-        o[1 + a] = trade_proc(1, 0.f); o[1 + n + a] = trade_proc(1, 1.f);
+        o[1 + a] = trade_proc(1, 0.0); o[1 + n + a] = trade_proc(1, 1.0);
     }
 }
 
@@ -370,11 +372,11 @@ __global__ void trade_observe_kernel(TradeParams R) {
     const int n = R.n, S = 1 + 2 * n;
     const size_t E = R.E;
     float *oraw = R.obs_raw + (size_t)env * S, *o = R.obs + (size_t)env * S;
-    float cash = R.cash[env];
-    oraw[0] = cash; o[0] = trade_proc(0, cash);
+    const double cash = R.cash[env];
+    oraw[0] = (float)cash; o[0] = trade_proc(0, cash);
     for (int a = 0; a < n; ++a) {
-        float q = R.q[a * E + env], p = R.p[a * E + env];
-        oraw[1 + a] = q; oraw[1 + n + a] = p;
+        const double q = R.q[a * E + env], p = R.p[a * E + env];
+        oraw[1 + a] = (float)q; oraw[1 + n + a] = (float)p;
         o[1 + a] = trade_proc(1, q); o[1 + n + a] = trade_proc(1, p);
     }
 }
@@ -392,7 +394,7 @@ static TradeParams trade_params(grl_handle *h) {
 int trade_alloc(grl_handle *h) {
     size_t E = h->E, n = h->cfg.n_assets;
     double sp = h->cfg.trade_std_p;
-    h->tr.std_e = (float)sqrt((sp * sp) * (1 - 0.9 * 0.9));   // fed_env.py:277-278
+    h->tr.std_e = sqrt((sp * sp) * (1 - 0.9 * 0.9));   // fed_env.py:277-278
     int rc;
     if ((rc = dmalloc(h, &h->tr.cash, E))) return rc;
     if ((rc = dmalloc(h, &h->tr.assets, E))) return rc;

@@ -424,7 +424,9 @@ __global__ __launch_bounds__(256) void heads_forward_kernel(const float *__restr
 #pragma unroll
         for (int a = 0; a < A; ++a) { wm[j][a] = muw[k * A + a]; ws[j][a] = sgw[k * A + a]; }
     }
-    const float4 wv = reinterpret_cast<const float4 *>(v3w)[lane];
+    // four scalar loads: v3_w sits at 1 026 A + a multiple of 4 floats in the flat parameter vector (tf.trainable_variables()
+    // order), i.e. only 8-byte aligned for an odd A -- a 16-byte vector load there would be a misaligned access
+    const float4 wv = make_float4(v3w[4 * lane], v3w[4 * lane + 1], v3w[4 * lane + 2], v3w[4 * lane + 3]);
     float4 x0[kHeadRows], x1[kHeadRows], xv[kHeadRows];
 #pragma unroll
     for (int r = 0; r < kHeadRows; ++r) {
@@ -706,6 +708,7 @@ int grl_net_create(grl_handle *h, const grl_net_config *cfg, grl_net **out) {
     n->ro_lb = nullptr; n->slab_floats = 0; n->w3t = n->w2t = nullptr;
     n->mu = n->sigma = n->vs = nullptr;
     n->keep_level = 0;
+    n->ar_ev0 = n->ar_ev1 = nullptr; n->ar_pending = 0; n->ar_calls = 0; n->ar_ms_total = 0.0; n->ar_ms_last = 0.f;
     n->keep = nullptr; n->keep_slots = 0; n->param_version = 0; n->keep_version = -1;
     n->shared_trunk = (cfg->reserved & GRL_NET_F_PER_AGENT_TRUNK) ? 0 : 1;     // the plain per-agent evaluation is the A/B reference
     n->cur_lane = 0; n->last_lane = 0;
@@ -779,6 +782,7 @@ int grl_net_destroy(grl_net *n) {
         if (n->ev_join[k]) hipEventDestroy(n->ev_join[k]);
     }
     if (n->ev_fork) hipEventDestroy(n->ev_fork);
+    if (n->ar_ev0) { hipEventDestroy(n->ar_ev0); hipEventDestroy(n->ar_ev1); }
     for (void *p : n->allocs) hipFree(p);
     if (n->keep) hipFree(n->keep);
     for (hipEvent_t ev : n->prof_ev) hipEventDestroy(ev);

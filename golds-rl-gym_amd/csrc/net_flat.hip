@@ -179,6 +179,11 @@ struct grl_fnet {
     int last_n;                    // samples of the last gradient pass (grl_fnet_apply_grads normalises the loss sums with it)
     void *comm;                    // ncclComm_t (RCCL): one all-reduce of the flat gradient per rollout, or nullptr
     int comm_world, comm_rank;
+    hipEvent_t ar_ev0, ar_ev1;     // bracket the all-reduce on the handle's stream (grl_fnet_comm_info)
+    int ar_pending;
+    long ar_calls;
+    double ar_ms_total;
+    float ar_ms_last;
     std::vector<void *> allocs;
 };
 
@@ -252,9 +257,13 @@ static int train_grads_device(grl_fnet *net, int n, const float *states, const f
 static int fcomm_allreduce_grads(grl_fnet *net, float *grad_scale_out) {
     *grad_scale_out = 1.0f;
     if (!net->comm) return GRL_OK;
+    if (!net->ar_ev0) { FNET_HIP(net, hipEventCreate(&net->ar_ev0)); FNET_HIP(net, hipEventCreate(&net->ar_ev1)); }
+    FNET_HIP(net, hipEventRecord(net->ar_ev0, net->h->stream));
     ncclResult_t r = ncclAllReduce(net->grads, net->grads, (size_t)net->off.total, ncclFloat, ncclSum, (ncclComm_t)net->comm, net->h->stream);
     (void)hipGetLastError();   // RCCL probes may leave a stale HIP error on this thread
     if (r != ncclSuccess) return ffail(net, GRL_E_COMM, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
+    FNET_HIP(net, hipEventRecord(net->ar_ev1, net->h->stream));
+    net->ar_pending = 1;
     *grad_scale_out = 1.0f / (float)net->comm_world;
     return GRL_OK;
 }
@@ -274,6 +283,11 @@ static int train_apply_device(grl_fnet *net, float lr, int apply_update, float g
     }
     FNET_HIP(net, hipGetLastError());
     FNET_HIP(net, hipStreamSynchronize(st));
+    if (net->ar_pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, net->ar_ev0, net->ar_ev1) == hipSuccess) { net->ar_ms_last = ms; net->ar_ms_total += ms; net->ar_calls += 1; }
+        net->ar_pending = 0;
+    }
     if (stats_host) {
         float s[5];
         FNET_HIP(net, hipMemcpy(s, net->stats, sizeof(s), hipMemcpyDeviceToHost));
@@ -376,6 +390,7 @@ int grl_fnet_create(grl_handle *h, const grl_fnet_config *cfg, grl_fnet **out) {
     if (rc == GRL_OK) rc = falloc(n, &n->d_counter, 4);
     n->ro_graph = nullptr; n->ro_graph_T = 0; n->ro_graph_ep = false;
     n->last_n = 0; n->comm = nullptr; n->comm_world = 1; n->comm_rank = 0;
+    n->ar_ev0 = n->ar_ev1 = nullptr; n->ar_pending = 0; n->ar_calls = 0; n->ar_ms_total = 0.0; n->ar_ms_last = 0.f;
     hipError_t e = hipSuccess;
     if (rc == GRL_OK) e = hipFuncSetAttribute((const void *)flat_forward_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLAT_LDS_BYTES);
     if (rc == GRL_OK && e == hipSuccess)
@@ -402,6 +417,7 @@ int grl_fnet_destroy(grl_fnet *n) {
         ncclCommDestroy((ncclComm_t)n->comm);
         (void)hipGetLastError();   // RCCL teardown may leave a stale HIP error on this thread
     }
+    if (n->ar_ev0) { hipEventDestroy(n->ar_ev0); hipEventDestroy(n->ar_ev1); }
     for (void *p : n->allocs) hipFree(p);
     delete n;
     return GRL_OK;
@@ -613,6 +629,24 @@ int grl_fnet_comm_init(grl_fnet *net, const void *unique_id, size_t bytes, int32
     (void)hipGetLastError();
     if (r != ncclSuccess) return ffail(net, GRL_E_COMM, std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
     net->comm = (void *)comm; net->comm_world = world_size; net->comm_rank = rank;
+    return GRL_OK;
+}
+
+int grl_fnet_comm_info(grl_fnet *net, int32_t *count_out, int32_t *user_rank_out, int64_t *allreduce_calls_out,
+                       double *allreduce_ms_total_out, float *allreduce_ms_last_out) {
+    if (!net) return GRL_E_INVALID;
+    int count = 0, urank = -1;
+    if (net->comm) {
+        ncclResult_t r = ncclCommCount((ncclComm_t)net->comm, &count);
+        if (r == ncclSuccess) r = ncclCommUserRank((ncclComm_t)net->comm, &urank);
+        (void)hipGetLastError();
+        if (r != ncclSuccess) return ffail(net, GRL_E_COMM, std::string("ncclCommCount: ") + ncclGetErrorString(r));
+    }
+    if (count_out) *count_out = count;
+    if (user_rank_out) *user_rank_out = urank;
+    if (allreduce_calls_out) *allreduce_calls_out = net->ar_calls;
+    if (allreduce_ms_total_out) *allreduce_ms_total_out = net->ar_ms_total;
+    if (allreduce_ms_last_out) *allreduce_ms_last_out = net->ar_ms_last;
     return GRL_OK;
 }
 

@@ -119,7 +119,8 @@ def _ptr(a):
 
 _FIELD_DTYPE = {}
 for _k, _v in FLD.items():
-    if _k.startswith("SWARM_") or _k.startswith("RESET_") or _k in ("TICKER_CASH", "TICKER_ASSETS", "TICKER_QUANTITY"):
+    if _k.startswith("SWARM_") or _k.startswith("RESET_") or _k in ("TICKER_CASH", "TICKER_ASSETS", "TICKER_QUANTITY",
+                                                                     "TRADE_CASH", "TRADE_ASSETS", "TRADE_QUANTITY", "TRADE_PRICES"):
         _FIELD_DTYPE[_v] = np.float64
     elif _k in ("ELAPSED", "EPISODE", "SOLOW_TAPE_POS", "NHIST", "TICKER_IDX", "TICKER_START", "TICKER_START0"):
         _FIELD_DTYPE[_v] = np.int32

@@ -42,6 +42,7 @@ NET_SIGNATURES = {
     "grl_net_comm_init": (C.c_int, [_P, _P, _SZ, _I, _I]),
     "grl_net_comm_broadcast_params": (C.c_int, [_P, _I]),
     "grl_net_comm_destroy": (C.c_int, [_P]),
+    "grl_net_comm_info": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "grl_net_profile_enable": (C.c_int, [_P, _I]),
     "grl_net_profile_read": (C.c_int, [_P, C.POINTER(_I), C.POINTER(C.c_float), C.POINTER(C.c_double)]),
     "grl_net_profile_read_tags": (C.c_int, [_P, _I, _P, _P, _P]),
@@ -244,6 +245,13 @@ class ConvNet(object):
 
     def comm_broadcast_params(self, root=0):
         self._check(self.lib.grl_net_comm_broadcast_params(self.n, root))
+
+    def comm_info(self):
+        """What RCCL reports for the attached communicator (ranks = ncclCommCount, 0 without one) and the all-reduce timing."""
+        cnt, ur, calls, tot, last = C.c_int32(), C.c_int32(), C.c_int64(), C.c_double(), C.c_float()
+        self._check(self.lib.grl_net_comm_info(self.n, C.byref(cnt), C.byref(ur), C.byref(calls), C.byref(tot), C.byref(last)))
+        return {"rccl_ranks": cnt.value, "rccl_user_rank": ur.value, "allreduce_calls": calls.value,
+                "allreduce_ms_total": tot.value, "allreduce_ms_last": last.value}
 
     def comm_destroy(self):
         self._check(self.lib.grl_net_comm_destroy(self.n))

@@ -49,15 +49,21 @@ class ActorLearner(object):
         return 0.0
 
     def _open_summaries(self):
+        """One writer per rank, each in its own directory: rank 0 in debugging_folder (the reference's single writer,
+        actor_learner.py:29), rank r > 0 in debugging_folder/rank<r> for the `rl/reward` points of ITS env shard."""
         if self.summaries and self.summary_writer is None:
+            import os
             from .policy_monitor import ScalarWriter
-            self.summary_writer = ScalarWriter(self.debugging_folder)
+            rank = self.ranks.rank if self.ranks is not None else 0
+            folder = self.debugging_folder if rank == 0 else os.path.join(self.debugging_folder, "rank%d" % rank)
+            self.summary_writer = ScalarWriter(folder)
         return self.summary_writer
 
     def _log_update(self, stats):
-        """'global_norm' (actor_learner.py:83) and the loss terms of one update, keyed by global_step."""
+        """'global_norm' (actor_learner.py:83) and the loss terms of one update, keyed by global_step.  The values are
+        replicated over ranks (the gradient is all-reduced): rank 0 writes them once."""
         w = self.summary_writer
-        if w is None or not stats:
+        if w is None or not stats or (self.ranks is not None and self.ranks.rank != 0):
             return
         w.add_scalar("global_norm", stats["global_norm"], self.global_step)
         w.add_scalar("loss/total", stats["loss"], self.global_step)

@@ -142,7 +142,7 @@ class GridPAACLearner(PAACLearner):
         # thread; handles here are single-threaded, so the episode (its own 1-env handle) is played between two updates.
         pe, last_eval = None, time.time()
         eval_every = float(getattr(self, "eval_every", 0.0) or 0.0)
-        if eval_every > 0:
+        if eval_every > 0 and ranks.rank == 0:      # only rank 0 evaluates: the other ranks build neither the monitor nor its env
             from ...envs import make
             from ..state_processors import SwarmStateProcessor
             from .policy_monitor import ScalarWriter, SwarmPolicyMonitor

@@ -8,11 +8,21 @@ class _GradientExchange(object):
     """What both rollouts do with the gradient: RCCL all-reduce inside train_rollout when a communicator is attached to the net,
     otherwise (host_allreduce set) local gradient -> host sum over ranks -> clip + Adam on the mean of the ranks' means."""
     host_allreduce = None      # callable(flat float32 gradient) -> (summed gradient, world size)
+    ranks = None               # set with host_allreduce: the ranks agree on the outcome of the local pass before they exchange
 
     def _update(self):
         if self.host_allreduce is None:
             return self.net.train_rollout(self.lr)
-        self.net.train_rollout_grads()
+        err = None
+        try:
+            self.net.train_rollout_grads()
+        except Exception as e:       # noqa: BLE001 -- e.g. GRL_E_RANGE on this rank only
+            err = e
+        if self.ranks is not None and self.ranks.min(0 if err else 1) == 0:
+            # every rank leaves the update together: nobody is left waiting in the exchange, no replica is updated
+            raise err if err else RuntimeError("the gradient pass failed on another rank; no replica was updated")
+        if err:
+            raise err
         summed, world = self.host_allreduce(self.net.get_grads())
         self.net.set_grads(summed)
         return self.net.apply_grads(self.lr, 1.0 / world)

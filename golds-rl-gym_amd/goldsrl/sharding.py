@@ -2,7 +2,7 @@
 the reference), so -- exactly like the reference's `np.split(emulators, workers)`
 (fed_gym/agents/paac/runners.py:18-19) -- each rank owns a contiguous block of env ids.  Generator
 streams are keyed by GLOBAL env id, so a sharded run reproduces the single-GPU run bit for bit.
-Pure Python; exercised on CPU by tests/test_sharding_gloo.py (world_size 2, gloo)."""
+Pure Python; exercised on CPU by tests/test_sharding_gloo.py and tests/test_spawn_ranks.py (world size 2 and 3)."""
 
 
 def shard_range(total_envs, rank, world_size):

@@ -121,10 +121,12 @@ enum grl_field {
     GRL_FLD_SOLOW_Z0 = 21,      /* f32 (E,p)  z restored on reset under RESEED/SNAPSHOT */
     GRL_FLD_NHIST = 22,         /* i32 (E,)   states in the worker's history list (emulator_runner.py:50-63) */
     /* TradeAR1 (fed_env.py:323-330) */
-    GRL_FLD_TRADE_CASH = 32,    /* f32 (E,) */
-    GRL_FLD_TRADE_ASSETS = 33,  /* f32 (E,) */
-    GRL_FLD_TRADE_QUANTITY = 34,/* f32 (E,n) */
-    GRL_FLD_TRADE_PRICES = 35,  /* f32 (E,n) */
+    /* the account is float64 like the reference's numpy state: the reward is log(assets') - log(assets) of two nearly equal
+     * values, which float32 prices would leave at ~1e-4 relative */
+    GRL_FLD_TRADE_CASH = 32,    /* f64 (E,) */
+    GRL_FLD_TRADE_ASSETS = 33,  /* f64 (E,) */
+    GRL_FLD_TRADE_QUANTITY = 34,/* f64 (E,n) */
+    GRL_FLD_TRADE_PRICES = 35,  /* f64 (E,n) */
     GRL_FLD_TRADE_NORMALS = 36, /* f32 (E,n) N(0,1) draws for the NEXT step (GRL_F_INJECT_NOISE) */
     /* Ticker (account in float64 like the reference's numpy scalars) */
     GRL_FLD_TICKER_CASH = 48,     /* f64 (E,)   cash_balance */

@@ -92,6 +92,9 @@ int grl_fnet_read_rollout(grl_fnet *net, const char *which, void *host, size_t b
 int grl_fnet_comm_init(grl_fnet *net, const void *unique_id, size_t bytes, int32_t rank, int32_t world_size);
 int grl_fnet_comm_broadcast_params(grl_fnet *net, int32_t root);
 int grl_fnet_comm_destroy(grl_fnet *net);
+/* ncclCommCount / ncclCommUserRank of the attached communicator and the all-reduce timing, as grl_net_comm_info (goldsrl_net.h) */
+int grl_fnet_comm_info(grl_fnet *net, int32_t *count_out, int32_t *user_rank_out, int64_t *allreduce_calls_out,
+                       double *allreduce_ms_total_out, float *allreduce_ms_last_out);
 
 #ifdef __cplusplus
 }

@@ -95,7 +95,7 @@ int grl_net_rollout(grl_net *net, int32_t T, int32_t reward_layout);
  * stats_host (may be NULL) receives {loss, policy_loss, critic_loss_mean, global_norm}. Synchronous. */
 int grl_net_train_rollout(grl_net *net, float lr, float *stats_host);
 /* The same in two halves, for callers that exchange or post-process gradients themselves (bench.py's fallback when no
- * RCCL communicator can be formed sums them over ranks with torch.distributed/gloo on the host):
+ * RCCL communicator can be formed sums them over ranks on the host, goldsrl/distributed.py):
  * _grads: loss + backward over the last rollout only -- the LOCAL mean gradient is left in the net (grl_net_get_grads), stats
  *         are the local loss terms and the local gradient norm, nothing is updated;
  * grl_net_set_grads: upload a flat gradient;  grl_net_apply_grads: clip_by_global_norm(grad_scale * grads) + Adam(lr). */
@@ -119,14 +119,20 @@ int grl_net_read_activation(grl_net *net, const char *which, float *host, size_t
 
 /* ---- multi-GPU: one process per GPU, one RCCL all-reduce (sum, fp32) of the flat gradient per
  * rollout over xGMI (no counterpart in the reference, which is single-device: actor_learner.py:70-75).
- * Rank 0 calls grl_comm_unique_id and ships the bytes to the other ranks by any means (bench.py uses
- * torch.distributed/gloo broadcast); every rank then calls grl_net_comm_init.  Afterwards
- * grl_net_train_* all-reduces gradients before clip+Adam, so parameters stay replicated. */
+ * Rank 0 calls grl_comm_unique_id and ships the bytes to the other ranks by any means (goldsrl/distributed.py uses its own
+ * TCP store on MASTER_ADDR); every rank then calls grl_net_comm_init.  Afterwards grl_net_train_* all-reduces gradients before
+ * clip+Adam, so parameters stay replicated; the GEMMs' range flag is max-reduced in the same group, so a GRL_E_RANGE pass
+ * fails on EVERY rank and no replica is updated. */
 size_t grl_comm_unique_id_bytes(void);
 int grl_comm_unique_id(void *out, size_t bytes);
 int grl_net_comm_init(grl_net *net, const void *unique_id, size_t bytes, int32_t rank, int32_t world_size);
 int grl_net_comm_broadcast_params(grl_net *net, int32_t root);
 int grl_net_comm_destroy(grl_net *net);
+/* What RCCL itself says about the attached communicator: ncclCommCount / ncclCommUserRank (0 / -1 without one), and the
+ * gradient all-reduces so far: calls, summed and last duration in ms (HIP events around the collective on the handle's stream).
+ * Any out pointer may be NULL. */
+int grl_net_comm_info(grl_net *net, int32_t *count_out, int32_t *user_rank_out, int64_t *allreduce_calls_out,
+                      double *allreduce_ms_total_out, float *allreduce_ms_last_out);
 
 /* Per-kernel timing of the GEMM kernels for bench.py's roofline (HIP events around every launch
  * of gemm_rowk / gemm_tn while enabled): returns launches, summed ms and summed FLOPs. */

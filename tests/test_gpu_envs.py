@@ -394,7 +394,7 @@ def test_trade_steps_golden(golden, n):
         eng.set_state("TRADE_NORMALS", g[k_ + "normals"][t][None])
         eng.step(g[k_ + "actions"][t][None].astype(np.float32))
         np.testing.assert_allclose(eng.read("obs_raw")[0], g[k_ + "obs"][t], rtol=1e-5, atol=1e-6)
-        np.testing.assert_allclose(eng.read("reward")[0], g[k_ + "reward"][t], rtol=1e-4, atol=2e-6)
+        np.testing.assert_allclose(eng.read("reward")[0], g[k_ + "reward"][t], rtol=1e-5, atol=1e-9)     # float64 account on the device
         assert bool(eng.read("done")[0]) == bool(g[k_ + "done"][t])
     if n == 2:
         np.testing.assert_allclose(eng.read("obs")[0], O.trade_process_state(eng.read("obs_raw")[0]), rtol=1e-5, atol=1e-6)
@@ -408,7 +408,7 @@ def test_trade_depletion_done_and_autoreset(golden):
         eng.set_state("TRADE_NORMALS", g["dep_normals"][t][None])
         eng.step(g["dep_actions"][t][None].astype(np.float32))
         assert bool(eng.read("done")[0]) == bool(g["dep_done"][t])
-        np.testing.assert_allclose(eng.read("reward")[0], g["dep_reward"][t], rtol=1e-4, atol=2e-6)
+        np.testing.assert_allclose(eng.read("reward")[0], g["dep_reward"][t], rtol=1e-5, atol=1e-9)
         if not g["dep_done"][t]:
             np.testing.assert_allclose(eng.read("obs_raw")[0], g["dep_obs"][t], rtol=1e-5, atol=1e-30)
     # auto-reset: observation is the reset one (quirk Q6)
@@ -441,7 +441,7 @@ def test_trade_batch_vs_oracle_and_price_moments():
         cash, assets, q, p, obs, rew, done = O.trade_step(cash, assets, q, p, act.astype(np.float64), nrm.astype(np.float64), O.trade_std_e())
         assert not done.any()
         np.testing.assert_allclose(eng.read("obs_raw"), obs, rtol=2e-5, atol=2e-6)
-        np.testing.assert_allclose(eng.read("reward"), rew, rtol=1e-3, atol=5e-6)
+        np.testing.assert_allclose(eng.read("reward"), rew, rtol=1e-5, atol=1e-9)
     # device generator: stationary std of log-prices stays below 2*std_p (tests/env_tests.py:115-124)
     eng2 = trade_engine(4096, n_assets=2, seed=5)
     eng2.reset()

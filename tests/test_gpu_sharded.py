@@ -3,7 +3,7 @@
     sum over ranks of (gradient of the rank's mean loss) / world == full-batch gradient,
 the clip is applied after the reduction and Adam runs replicated.  Checked for the conv net and the flat GRU net
 (a) in one process with two half-size handles (train_rollout_grads -> sum -> set_grads -> apply_grads(lr, 1/2)), and
-(b) with two fresh rank processes on device 0 exchanging through torch.distributed/gloo (the host path bench.py falls back
+(b) with two fresh rank processes on device 0 exchanging through the host store of goldsrl.distributed (the host path bench.py falls back
 to when RCCL cannot form a communicator; RCCL itself refuses two ranks on one device), against a single-process
 full-batch update.  Generator streams are keyed by global env id, so the sharded rollouts ARE the full-batch rollout."""
 import json
@@ -72,14 +72,14 @@ def test_two_half_handles_sum_to_the_full_batch_update(kind, E, T):
 
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("kind,E,T", CASES)
-def test_two_rank_processes_gloo_exchange_equals_full_batch(kind, E, T, tmp_path):
+def test_two_rank_processes_host_exchange_equals_full_batch(kind, E, T, tmp_path):
     from goldsrl import distributed as D
     updates = 2
-    rc = D.spawn_local_ranks([sys.executable, os.path.join(ROOT, "tests", "_shard_rank.py"), kind, str(E), str(T), str(updates), "gloo",
+    rc = D.spawn_local_ranks([sys.executable, os.path.join(ROOT, "tests", "_shard_rank.py"), kind, str(E), str(T), str(updates), "host",
                               str(tmp_path)], 2)
     assert rc == 0
     r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
-    assert str(r0["exchange"]) == "gloo-host-fallback" and int(r0["world"]) == 2
+    assert str(r0["exchange"]) == "host-store-fallback" and int(r0["world"]) == 2
     assert np.array_equal(r0["params"], r1["params"])
     p_full, g_full, st_full = _full_batch(kind, E, T, updates)
     scale = np.abs(g_full).max()
@@ -95,7 +95,7 @@ def test_rccl_attempt_on_one_device_falls_back_loudly_not_silently(tmp_path):
     rc = D.spawn_local_ranks([sys.executable, os.path.join(ROOT, "tests", "_shard_rank.py"), "solow", "64", "3", "1", "rccl", str(tmp_path)], 2)
     assert rc == 0
     r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
-    assert str(r0["exchange"]) == str(r1["exchange"]) == "gloo-host-fallback"
+    assert str(r0["exchange"]) == str(r1["exchange"]) == "host-store-fallback"
     assert np.array_equal(r0["params"], r1["params"])
 
 
@@ -109,7 +109,7 @@ def test_bench_gpus_2_without_a_launcher_reports_two_ranks():
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     j = json.loads(lines[0])
-    assert j["n_gpus"] == 2 and j["config"]["gradient_exchange"] in ("rccl", "gloo-host-fallback")
+    assert j["n_gpus"] == 2 and j["config"]["gradient_exchange"] in ("rccl", "host-store-fallback")
     assert j["config"]["envs_total"] == 512 and j["value"] > 0
     assert j["strong_scaling"]["envs_total"] == 256 and j["strong_scaling"]["envs_per_gpu"] == 128
     assert j["roofline"]["frac"] > 0
@@ -124,7 +124,7 @@ def test_flat_learner_sharded_over_two_ranks(tmp_path):
     rc = D.spawn_local_ranks([sys.executable, os.path.join(ROOT, "tests", "_learner_rank.py"), str(E), str(T), str(U), str(tmp_path), "flat"], 2)
     assert rc == 0
     r0, r1 = np.load(tmp_path / "learner_rank0.npz"), np.load(tmp_path / "learner_rank1.npz")
-    assert str(r0["exchange"]) == "gloo-host-fallback" and int(r0["global_step"]) == U * 2 * E * T
+    assert str(r0["exchange"]) == "host-store-fallback" and int(r0["global_step"]) == U * 2 * E * T
     assert np.array_equal(r0["params"], r1["params"])
     single = tmp_path / "single"
     single.mkdir()
@@ -148,7 +148,7 @@ def test_grid_learner_sharded_over_two_ranks(tmp_path):
     rc = D.spawn_local_ranks([sys.executable, os.path.join(ROOT, "tests", "_learner_rank.py"), str(E), str(T), str(U), str(tmp_path)], 2)
     assert rc == 0
     r0, r1 = np.load(tmp_path / "learner_rank0.npz"), np.load(tmp_path / "learner_rank1.npz")
-    assert str(r0["exchange"]) == "gloo-host-fallback" and int(r0["global_step"]) == int(r1["global_step"]) == U * 2 * E * T
+    assert str(r0["exchange"]) == "host-store-fallback" and int(r0["global_step"]) == int(r1["global_step"]) == U * 2 * E * T
     assert np.array_equal(r0["params"], r1["params"])
     single = tmp_path / "single"
     single.mkdir()

@@ -1,4 +1,4 @@
-"""CPU: the N>1 launch path of bench.py without a launcher -- `spawn_local_ranks` starts fresh rank processes with
+"""CPU: the N>1 host layer (goldsrl/distributed.py: standard library only) and the launch path of bench.py without a launcher -- `spawn_local_ranks` starts fresh rank processes with
 RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, a failing rank stops the job with its exit code, and bench.py refuses a
 WORLD_SIZE that contradicts --gpus.  No GPU is touched (the children are tiny scripts / the refusal happens before any import
 of the engine)."""
@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "golds-rl-gym_amd"))
 
 
-def test_spawn_sets_rank_environment_and_forms_a_gloo_group(tmp_path):
+def test_spawn_sets_rank_environment_and_the_ranks_meet_over_the_store(tmp_path):
     from goldsrl import distributed as D
     child = tmp_path / "child.py"
     child.write_text(
@@ -46,3 +46,135 @@ def test_bench_refuses_world_size_that_contradicts_gpus():
     env = dict(os.environ, WORLD_SIZE="1", RANK="0")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
     assert p.returncode != 0 and "WORLD_SIZE=1" in p.stderr and p.stdout.strip() == ""
+
+
+_STORE_CHILD = (
+    "import os, sys, struct\n"
+    "import numpy as np\n"
+    "sys.path.insert(0, %r)\n"
+    "from goldsrl import distributed as D\n"
+    "assert 'torch' not in sys.modules\n"
+    "r = D.Ranks().init(timeout_s=120)\n"
+    "w = r.world\n"
+    "assert r.max(1.0 + r.rank) == float(w) and r.min(1.0 + r.rank) == 1.0 and r.sum(1.0 + r.rank) == w * (w + 1) / 2\n"
+    "parts = r.allgather_bytes(bytes([r.rank]) * (r.rank + 1))\n"
+    "assert parts == [bytes([k]) * (k + 1) for k in range(w)]\n"
+    "uid = np.arange(128, dtype=np.uint8) if r.rank == 0 else np.zeros(128, np.uint8)\n"
+    "assert np.array_equal(np.frombuffer(r.broadcast_bytes(uid.tobytes(), 0), np.uint8), np.arange(128, dtype=np.uint8))\n"
+    "g = np.full(2210213, 0.25 * (r.rank + 1), np.float32)\n"          # the conv net's flat gradient size
+    "s = r.allreduce_sum_f32(g)\n"
+    "assert s.shape == g.shape and (s == 0.25 * w * (w + 1) / 2).all()\n"
+    "p = r.broadcast_array(np.arange(7, dtype=np.float32) * (1 + r.rank), 0)\n"
+    "assert np.array_equal(p, np.arange(7, dtype=np.float32))\n"
+    "r.barrier()\n"
+    "assert 'torch' not in sys.modules\n"
+    "open(os.path.join(%r, 'ok%%d' %% r.rank), 'w').write('ok')\n"
+    "r.close()\n")
+
+
+def test_store_collectives_world_3(tmp_path):
+    from goldsrl import distributed as D
+    child = tmp_path / "child.py"
+    child.write_text(_STORE_CHILD % (os.path.join(ROOT, "golds-rl-gym_amd"), str(tmp_path)))
+    assert D.spawn_local_ranks([sys.executable, str(child)], 3) == 0
+    assert sorted(p.name for p in tmp_path.iterdir() if p.name.startswith("ok")) == ["ok0", "ok1", "ok2"]
+
+
+def test_store_on_a_fixed_port(tmp_path):
+    """GRL_STORE_PORT: the multi-node form (every rank connects to MASTER_ADDR on a given port, no rendezvous file)."""
+    import socket
+    from goldsrl import distributed as D
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    child = tmp_path / "child.py"
+    child.write_text(_STORE_CHILD % (os.path.join(ROOT, "golds-rl-gym_amd"), str(tmp_path)))
+    assert D.spawn_local_ranks([sys.executable, str(child)], 2, extra_env={"GRL_STORE_PORT": str(port)}) == 0
+    assert sorted(p.name for p in tmp_path.iterdir() if p.name.startswith("ok")) == ["ok0", "ok1"]
+
+
+def test_store_under_the_drivers_elastic_launcher(tmp_path):
+    """The driver starts bench.py's ranks with `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P`: MASTER_PORT is then held by the launcher's own store, and the ranks (which never import it)
+    must still meet -- through the ephemeral port rank 0 publishes for its siblings."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    child = tmp_path / "child.py"
+    child.write_text(_STORE_CHILD % (os.path.join(ROOT, "golds-rl-gym_amd"), str(tmp_path)))
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "GRL_RDZV_KEY", "GRL_STORE_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), str(child)], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert sorted(q.name for q in tmp_path.iterdir() if q.name.startswith("ok")) == ["ok0", "ok1"]
+
+
+class _FakeNet(object):
+    """Stands for a ConvNet / FlatNet binding in the phase logic of attach_gradient_exchange (no GPU here)."""
+
+    class _Lib(object):
+        @staticmethod
+        def grl_comm_unique_id_bytes():
+            return 128
+
+    def __init__(self, rank, fail_init_on):
+        import numpy as np
+        self.lib, self.rank, self.fail_init_on = self._Lib(), rank, fail_init_on
+        self.params = np.full(5, float(rank + 1), np.float32)
+        self.calls = []
+
+    def comm_unique_id(self):
+        import numpy as np
+        self.calls.append("uid")
+        return np.arange(128, dtype=np.uint8)
+
+    def comm_init(self, uid, rank, world):
+        import numpy as np
+        assert np.array_equal(np.asarray(uid), np.arange(128, dtype=np.uint8))
+        self.calls.append("init")
+        if rank in self.fail_init_on:
+            raise RuntimeError("ncclCommInitRank: refused (test)")
+
+    def comm_info(self):
+        return {"rccl_ranks": int(os.environ["WORLD_SIZE"]), "rccl_user_rank": self.rank}
+
+    def comm_broadcast_params(self, root):
+        self.calls.append("bcast")
+
+    def comm_destroy(self):
+        self.calls.append("destroy")
+
+    def get_params(self):
+        return self.params
+
+    def set_params(self, p):
+        self.params = p
+
+
+def test_exchange_setup_phases_keep_the_ranks_together(tmp_path):
+    """attach_gradient_exchange: one rank failing ncclCommInitRank sends EVERY rank to the host path (the rank that formed a
+    communicator destroys it), parameters come from rank 0, and the host sum is world x the mean."""
+    from goldsrl import distributed as D
+    child = tmp_path / "child.py"
+    child.write_text(
+        "import os, sys\n"
+        "import numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from goldsrl import distributed as D\n"
+        "from test_spawn_ranks import _FakeNet\n"
+        "r = D.Ranks().init(timeout_s=120)\n"
+        "class Roll(object):\n"
+        "    host_allreduce = None\n"
+        "roll = Roll(); roll.net = _FakeNet(r.rank, fail_init_on={1})\n"
+        "assert D.attach_gradient_exchange(roll, r) == 'host-store-fallback'\n"
+        "assert roll.net.calls == (['uid', 'init', 'destroy'] if r.rank == 0 else ['init'])\n"
+        "assert np.array_equal(roll.net.params, np.full(5, 1.0, np.float32))\n"
+        "g, world = roll.host_allreduce(np.full(3, r.rank + 1.0, np.float32))\n"
+        "assert world == 2 and (g == 3.0).all()\n"
+        "roll2 = Roll(); roll2.net = _FakeNet(r.rank, fail_init_on=set())\n"
+        "assert D.attach_gradient_exchange(roll2, r) == 'rccl' and roll2.net.calls[-1] == 'bcast' and roll2.host_allreduce is None\n"
+        "roll3 = Roll(); roll3.net = _FakeNet(r.rank, fail_init_on=set())\n"
+        "assert D.attach_gradient_exchange(roll3, r, prefer='host') == 'host-store-fallback' and 'init' not in roll3.net.calls\n"
+        "open(os.path.join(%r, 'ok%%d' %% r.rank), 'w').write('ok')\n"
+        "r.close()\n" % (os.path.join(ROOT, "golds-rl-gym_amd"), os.path.join(ROOT, "tests"), str(tmp_path)))
+    assert D.spawn_local_ranks([sys.executable, str(child)], 2) == 0
+    assert sorted(p.name for p in tmp_path.iterdir() if p.name.startswith("ok")) == ["ok0", "ok1"]
