@@ -9,6 +9,7 @@
 #include <cmath>
 
 #include "common.h"
+#include "rollout_dev.h"
 
 static thread_local std::string g_create_error;
 static std::mutex g_live_mutex;
@@ -132,33 +133,7 @@ __global__ void episodes_account_kernel(const float *__restrict__ reward, const 
                                         grl_episode_record *__restrict__ rec, int32_t *__restrict__ count, int cap) {
     const int e = env_base + blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = e < E;
-    double t = 0.0;
-    int32_t l = 0;
-    int64_t s = 0;
-    bool fin = false;
-    if (active) {
-        t = total[e] + (double)reward[e];
-        l = len[e] + 1;
-        s = steps[e] + 1;
-        fin = done[e] != 0;
-    }
-    const unsigned long long m = __ballot(fin);
-    if (m) {
-        const int lane = threadIdx.x & 63;
-        int base = 0;
-        if (lane == __ffsll((long long)m) - 1) base = atomicAdd(count, __popcll(m));
-        base = __shfl(base, __ffsll((long long)m) - 1);
-        if (fin) {
-            const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
-            if (slot < cap) {
-                grl_episode_record r;
-                r.step_index = s; r.env = e; r.length = l; r.total_reward = t;
-                rec[slot] = r;
-            }
-            t = 0.0; l = 0;
-        }
-    }
-    if (active) { total[e] = t; len[e] = l; steps[e] = s; }
+    episodes_account_env(active, e, active ? reward[e] : 0.f, active && done[e] != 0, total, len, steps, rec, count, cap);
 }
 
 int episodes_launch_account(grl_handle *h, int env_base, int count) {

@@ -5,49 +5,17 @@
 // All are one-pass HBM-bound kernels: 20 B per (t,b) for the returns.
 #include "common.h"
 #include "rng.h"
+#include "rollout_dev.h"
 
 namespace grl {
 
-// One lane per column b; walks t = T-1..0 with a float64 running return like the reference's
-// float64 numpy arrays, including its one float32 product gamma*V(s_T) (bootstrap value is the
-// net's float32 output; pinned by tests/golden/returns.npz).
 __global__ __launch_bounds__(256) void returns_kernel(const float *__restrict__ r, const float *__restrict__ v,
                                                       const float *__restrict__ mask, const float *__restrict__ boot,
                                                       int T, int B, float gamma, float lam, float scale, float clip_lo,
                                                       float clip_hi, float *__restrict__ y, float *__restrict__ adv) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    const bool clip = clip_lo < clip_hi;
-    const double g = (double)gamma;
-    if (lam == 1.0f) {
-        double est = 0.0;
-        for (int t = T - 1; t >= 0; --t) {
-            size_t i = (size_t)t * B + b;
-            float rew = r[i];
-            if (clip) rew = rew > clip_hi ? clip_hi : (rew < clip_lo ? clip_lo : rew);   // rescale_reward
-            double ge = (t == T - 1) ? (double)(gamma * boot[b]) : g * est;
-            if (mask) ge = ge * (double)mask[i];
-            est = (double)rew + ge;
-            y[i] = (float)est;
-            adv[i] = (float)((est - (double)v[i]) / (double)scale);
-        }
-    } else {
-        // GAE: delta_t = r_t + g V_{t+1} - V_t ; A_t = delta_t + g*lam*A_{t+1} ; target = A_t + V_t
-        double run = 0.0, vnext = (double)boot[b];
-        const double gl = g * (double)lam;
-        for (int t = T - 1; t >= 0; --t) {
-            size_t i = (size_t)t * B + b;
-            float rew = r[i];
-            if (clip) rew = rew > clip_hi ? clip_hi : (rew < clip_lo ? clip_lo : rew);
-            double m = mask ? (double)mask[i] : 1.0;
-            double vt = (double)v[i];
-            double delta = (double)rew + g * vnext * m - vt;
-            run = delta + gl * m * run;
-            y[i] = (float)(run + vt);
-            adv[i] = (float)(run / (double)scale);
-            vnext = vt;
-        }
-    }
+    returns_column(r + b, v + b, mask ? mask + b : nullptr, B, boot[b], T, gamma, lam, scale, clip_lo, clip_hi, y + b, adv + b, B);
 }
 
 int launch_returns(grl_handle *h, const float *r, const float *v, const float *mask, const float *boot, int T, int B,

@@ -198,3 +198,64 @@ def test_trade_rollout_with_the_a3c_workers_gae():
     assert np.abs(rews).max() > 0 and np.isfinite(net.train_rollout(1e-4)["loss"])
     with pytest.raises(_ffi.GrlError):
         _ffi_flat.FlatNet(eng, static_size=S, temporal_size=S, rnn_length=R, num_actions=n, gae_lambda=0.0)
+
+
+def _flat_job(kind, E, T, cap, mode, monkeypatch):
+    """One engine + FlatNet + three rollouts (with R6 accounting on); mode 'graph' keeps the launch-per-stage rollout."""
+    from goldsrl import _ffi
+    from goldsrl import rollout as R
+    if mode == "graph":
+        monkeypatch.setenv("GRL_FLAT_ROLLOUT", "graph")
+    else:
+        monkeypatch.delenv("GRL_FLAT_ROLLOUT", raising=False)
+    if kind == "solow":
+        eng = _ffi.Engine(_ffi.ENV_SOLOW, E, seed=21, max_episode_steps=cap, solow_tape_len=64)
+    else:
+        eng = _ffi.Engine(_ffi.ENV_TRADE, E, seed=21, n_assets=16, rnn_length=20, max_episode_steps=cap)
+    eng.reset()
+    eng.episodes_enable(capacity=8 * E)
+    roll = R.FlatPolicyRollout(eng, T, train=False)
+    out = []
+    A = roll.net.cfg.num_actions
+    S0 = roll.net.cfg.static_size
+    for _ in range(3):
+        roll.run(); eng.wait()
+        d = {k: roll.net.read_rollout(k, (T, E)) for k in ("values", "rewards", "masks", "y", "adv")}
+        d["actions"] = roll.net.read_rollout("actions", (T, E, A))
+        d["states"] = roll.net.read_rollout("states", (T, E, S0))
+        d["boot"] = roll.net.read_rollout("boot", (E,))
+        if kind == "solow":
+            d["histories"] = roll.net.read_rollout("histories", (T, E, 5, 2))
+            for f in ("SOLOW_K", "SOLOW_Z", "SOLOW_E", "SOLOW_TAPE", "SOLOW_TAPE_POS", "NHIST", "ELAPSED", "EPISODE"):
+                d["st_" + f] = eng.get_state(f)
+        else:
+            d["nhist"] = roll.net.read_rollout("nhist", (T, E)).view(np.int32)
+            for f in ("TRADE_CASH", "TRADE_ASSETS", "TRADE_QUANTITY", "TRADE_PRICES", "NHIST", "ELAPSED", "EPISODE"):
+                d["st_" + f] = eng.get_state(f)
+        for o in ("obs", "obs_raw", "reward", "done"):
+            d["out_" + o] = eng.read(o)
+        d["done_list"] = np.sort(eng.read("done_list")[:int(eng.read("done_count")[0])])
+        recs = eng.episodes_read()
+        d["recs"] = np.array([(int(r["step_index"]), int(r["env"]), int(r["length"]), float(r["total_reward"])) for r in recs])
+        out.append(d)
+    pred = roll.net.predict_env()
+    roll.net.close(); eng.close()
+    return out, pred
+
+
+@pytest.mark.parametrize("kind,E,cap", [("solow", 200, 7), ("solow", 4096, 1024), ("trade", 200, 9), ("trade", 1000, 1024)])
+def test_persistent_rollout_is_bit_identical_to_the_graph_of_launches(kind, E, cap, monkeypatch):
+    """The T-step actor loop as ONE kernel (a workgroup keeps 64 envs for the whole rollout) against the launch-per-stage
+    rollout it replaces: every rollout buffer, the env state, the handle's outputs, the done list and the R6 records, over three
+    consecutive rollouts with TimeLimit resets (and Solow tape refills) inside them; E = 200 leaves the last group partial."""
+    T = 20
+    a, pa = _flat_job(kind, E, T, cap, "persistent", monkeypatch)
+    b, pb = _flat_job(kind, E, T, cap, "graph", monkeypatch)
+    for u, (da, db) in enumerate(zip(a, b)):
+        assert sorted(da) == sorted(db)
+        for k in da:
+            assert np.array_equal(da[k], db[k]), (kind, u, k)
+    for k in pa:
+        assert np.array_equal(pa[k], pb[k])
+    if cap < 20:      # episodes ended inside the rollouts: resets, tape refills and R6 records were exercised
+        assert sum(len(d["recs"]) for d in a) >= 2 * E
