@@ -85,6 +85,7 @@ struct FlatArgs {
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 #include "net_flat_mfma.inc"
+#include "net_flat_fast.inc"
 #include "net_flat_rollout.inc"
 
 __global__ void flat_slab_reduce_kernel(const float *__restrict__ slab, int blocks, long n, float *__restrict__ dst) {
@@ -179,8 +180,12 @@ struct grl_fnet {
     hipGraphExec_t ro_graph;       // the T-step rollout captured once and replayed (launch-bound at 4 096 envs)
     int ro_graph_T;
     bool ro_graph_ep;              // the captured rollout contains the R6 accounting launches
+    int fast_forward;              // 1: synthesized-window forwards use net_flat_fast.inc (GRL_FLAT_FORWARD=layers: the layer-by-layer form)
     int ro_persistent;             // 1: the T-step actor loop is ONE persistent kernel (net_flat_rollout.inc); 0: the hipGraph of launches
     size_t ro_lds_set;             // dynamic LDS size the rollout kernel's attribute is set to
+    void *d_roargs;                // RolloutArgs of the persistent rollout, in device memory
+    long long *d_ts;               // stage timestamps of workgroup 0 of the persistent rollout (debug: grl_fnet_rollout_stage_times)
+    int *d_ts_n;
     int last_n;                    // samples of the last gradient pass (grl_fnet_apply_grads normalises the loss sums with it)
     void *comm;                    // ncclComm_t (RCCL): one all-reduce of the flat gradient per rollout, or nullptr
     int comm_world, comm_rank;
@@ -225,6 +230,12 @@ static int launch_forward(grl_fnet *net, int n, const float *states, const float
                           const int32_t *nhist = nullptr) {
     FlatArgs a = base_args(net, n, states, hist, mu, sigma, vs, save, nhist);
     const int groups = (n + 63) / 64;
+    if (nhist && net->cfg.static_size == net->cfg.temporal_size && net->fast_forward) {
+        // synthesized window (the PAAC worker's: the current state repeated): the 2T + 5 stage form of net_flat_fast.inc
+        hipLaunchKernelGGL(flat_forward_fast_kernel, dim3(groups), dim3(FNT), ff_lds_bytes(net->cfg.static_size), net->h->stream, a);
+        FNET_HIP(net, hipGetLastError());
+        return GRL_OK;
+    }
     const size_t wbytes = (size_t)(net->cfg.temporal_size + FH) * 3 * FH * sizeof(float);
     static const int wlds_max_groups = getenv("GRL_FLAT_WLDS_GROUPS") ? atoi(getenv("GRL_FLAT_WLDS_GROUPS")) : 256;      // one workgroup per CU; measured (tools/bench_trade_sizes.py): 128 / 256 groups 7.6 -> 5.5 ms, 384 / 512 groups 8.5 -> 10.4 ms
     if (groups <= wlds_max_groups)
@@ -323,13 +334,12 @@ static int enqueue_rollout(grl_fnet *net, int T) {
         // states[t] = shared_states, histories[t] = shared_histories (paac.py:132-133).  For TradeAR1 the window is
         // kept as (state, #rows): the worker's history is min(n, rnn) copies of the current state (quirk Q11)
         FNET_HIP(net, hipMemcpyAsync(net->ro_states + (size_t)t * E * S0, obs, (size_t)E * S0 * 4, hipMemcpyDeviceToDevice, st));
-        if (solow) {
-            FNET_HIP(net, hipMemcpyAsync(net->ro_hist + (size_t)t * E * R * 2, h->so.history, (size_t)E * R * 8, hipMemcpyDeviceToDevice, st));
-            rc = launch_forward(net, E, obs, h->so.history, net->mu, net->sigma, net->ro_val + (size_t)t * E, false);
-        } else {
-            FNET_HIP(net, hipMemcpyAsync(net->ro_nhist + (size_t)t * E, h->tr.nhist, (size_t)E * 4, hipMemcpyDeviceToDevice, st));
-            rc = launch_forward(net, E, obs, nullptr, net->mu, net->sigma, net->ro_val + (size_t)t * E, false, h->tr.nhist);
-        }
+        // the window is kept as (state, #rows) for both envs -- the worker's history is min(n, rnn) copies of the current state
+        // (quirk Q11); Solow's dense (E, rnn, 2) form is recorded too (grl_fnet_read_rollout "histories")
+        const int32_t *nh = solow ? h->so.nhist : h->tr.nhist;
+        if (solow) FNET_HIP(net, hipMemcpyAsync(net->ro_hist + (size_t)t * E * R * 2, h->so.history, (size_t)E * R * 8, hipMemcpyDeviceToDevice, st));
+        FNET_HIP(net, hipMemcpyAsync(net->ro_nhist + (size_t)t * E, nh, (size_t)E * 4, hipMemcpyDeviceToDevice, st));
+        rc = launch_forward(net, E, obs, nullptr, net->mu, net->sigma, net->ro_val + (size_t)t * E, false, nh);
         if (rc) return rc;
         hipLaunchKernelGGL(flat_sample_kernel, dim3((E * A + 255) / 256), dim3(256), 0, st, net->mu, net->sigma, E, A, h->cfg.seed,
                            (uint32_t)h->cfg.env_id_offset, (const uint32_t *)net->d_counter, (uint32_t)t, h->cfg.env_kind,
@@ -340,8 +350,7 @@ static int enqueue_rollout(grl_fnet *net, int T) {
         FNET_HIP(net, hipMemcpyAsync(net->ro_rew + (size_t)t * E, h->reward, (size_t)E * 4, hipMemcpyDeviceToDevice, st));
         hipLaunchKernelGGL(flat_mask_kernel, dim3((E + 255) / 256), dim3(256), 0, st, h->done, E, net->ro_mask + (size_t)t * E);
     }
-    rc = solow ? launch_forward(net, E, obs, h->so.history, net->mu, net->sigma, net->ro_boot, false)
-               : launch_forward(net, E, obs, nullptr, net->mu, net->sigma, net->ro_boot, false, h->tr.nhist);
+    rc = launch_forward(net, E, obs, nullptr, net->mu, net->sigma, net->ro_boot, false, solow ? h->so.nhist : h->tr.nhist);
     if (rc) return rc;
     // rewards clipped to [-2, 2] (paac.py:145), masked n-step return (paac.py:167-172), adv / scale (paac.py:177)
     // gae_lambda < 1: the A3C worker's GAE on the raw rewards (a3c/worker.py:232-294)
@@ -361,7 +370,7 @@ static int launch_persistent_rollout(grl_fnet *net, int T) {
     R.f = base_args(net, h->E, nullptr, nullptr, nullptr, nullptr, nullptr, false);
     R.steps = T; R.env_kind = h->cfg.env_kind;
     const int n_assets = solow ? 0 : h->cfg.n_assets;
-    const size_t lds_bytes = (size_t)rollout_lds_floats(net->cfg.temporal_size, net->cfg.num_actions, T, n_assets, &R) * sizeof(float);
+    const size_t lds_bytes = (size_t)rollout_lds_floats(net->cfg.static_size, T, n_assets, &R) * sizeof(float);
     if (lds_bytes > 160 * 1024) return GRL_E_SIZE;
     if (lds_bytes > net->ro_lds_set) {
         if (hipFuncSetAttribute((const void *)flat_rollout_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) {
@@ -386,8 +395,15 @@ static int launch_persistent_rollout(grl_fnet *net, int T) {
     R.ep_total = h->ep_total; R.ep_len = h->ep_len; R.ep_steps = h->ep_steps; R.ep_rec = h->ep_rec; R.ep_count = h->ep_count;
     R.ep_cap = h->ep_capacity;
     hipStream_t st = h->stream;
+    R.ts = net->d_ts; R.ts_n = net->d_ts_n;
+    if (net->d_ts_n) FNET_HIP(net, hipMemsetAsync(net->d_ts_n, 0, sizeof(int), st));
     FNET_HIP(net, hipMemsetAsync(h->done_count, 0, sizeof(int32_t), st));      // the last step's done list is built inside the kernel
-    hipLaunchKernelGGL(flat_rollout_kernel, dim3((h->E + 63) / 64), dim3(256), lds_bytes, st, R);
+    if (!net->d_roargs) {
+        FNET_HIP(net, hipMalloc(&net->d_roargs, sizeof(RolloutArgs)));
+        net->allocs.push_back(net->d_roargs);
+    }
+    FNET_HIP(net, hipMemcpyAsync(net->d_roargs, &R, sizeof(RolloutArgs), hipMemcpyHostToDevice, st));      // pageable source: staged before the call returns
+    hipLaunchKernelGGL(flat_rollout_kernel, dim3((h->E + 63) / 64), dim3(FNT), lds_bytes, st, R.f, (const RolloutArgs *)net->d_roargs);
     FNET_HIP(net, hipGetLastError());
     return GRL_OK;
 }
@@ -437,7 +453,9 @@ int grl_fnet_create(grl_handle *h, const grl_fnet_config *cfg, grl_fnet **out) {
     {   // GRL_FLAT_ROLLOUT=graph keeps the launch-per-stage rollout (captured into a hipGraph) for A/B and for the equality tests
         const char *e = getenv("GRL_FLAT_ROLLOUT");
         n->ro_persistent = (e && strcmp(e, "graph") == 0) ? 0 : 1;
-        n->ro_lds_set = 0;
+        n->ro_lds_set = 0; n->d_ts = nullptr; n->d_ts_n = nullptr; n->d_roargs = nullptr;
+        const char *f = getenv("GRL_FLAT_FORWARD");
+        n->fast_forward = (f && strcmp(f, "layers") == 0) ? 0 : 1;
     }
     n->last_n = 0; n->comm = nullptr; n->comm_world = 1; n->comm_rank = 0;
     n->ar_ev0 = n->ar_ev1 = nullptr; n->ar_pending = 0; n->ar_calls = 0; n->ar_ms_total = 0.0; n->ar_ms_last = 0.f;
@@ -448,6 +466,8 @@ int grl_fnet_create(grl_handle *h, const grl_fnet_config *cfg, grl_fnet **out) {
                                 (int)(FLAT_LDS_BYTES + (size_t)(MAXD + FH) * 3 * FH * sizeof(float)));
     if (rc == GRL_OK && e == hipSuccess)
         e = hipFuncSetAttribute((const void *)flat_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLAT_LDS_BYTES);
+    if (rc == GRL_OK && e == hipSuccess)
+        e = hipFuncSetAttribute((const void *)flat_forward_fast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ff_lds_bytes(MAXS0));
     if (rc == GRL_OK && e != hipSuccess) rc = ffail(n, GRL_E_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
     if (rc != GRL_OK) {
         fail(h, rc, "grl_fnet_create: " + n->err);
@@ -562,7 +582,7 @@ int grl_fnet_predict_env(grl_fnet *net, float *mu, float *sigma, float *vs) {
     int rc = check_env(net);
     if (rc) return rc;
     grl_handle *h = net->h;
-    if (h->cfg.env_kind == GRL_ENV_SOLOW) rc = launch_forward(net, h->E, h->so.obs, h->so.history, net->mu, net->sigma, net->vs, false);
+    if (h->cfg.env_kind == GRL_ENV_SOLOW) rc = launch_forward(net, h->E, h->so.obs, nullptr, net->mu, net->sigma, net->vs, false, h->so.nhist);
     else rc = launch_forward(net, h->E, h->tr.obs, nullptr, net->mu, net->sigma, net->vs, false, h->tr.nhist);
     if (rc) return rc;
     return fdownload(net, h->E, mu, sigma, vs);
@@ -598,7 +618,7 @@ int grl_fnet_rollout(grl_fnet *net, int32_t T) {
         Al(&net->ro_envact, (size_t)E * A); Al(&net->ro_val, (size_t)T * E); Al(&net->ro_rew, (size_t)T * E); Al(&net->ro_mask, (size_t)T * E);
         Al(&net->ro_y, (size_t)T * E); Al(&net->ro_adv, (size_t)T * E); Al(&net->ro_boot, E);
         if (solow) Al(&net->ro_hist, (size_t)T * E * R * 2);
-        else if (rc == GRL_OK) rc = falloc(net, &net->ro_nhist, (size_t)T * E);
+        if (rc == GRL_OK) rc = falloc(net, &net->ro_nhist, (size_t)T * E);
         if (rc) return rc;
     }
     net->T = T;
@@ -645,12 +665,30 @@ int grl_fnet_rollout(grl_fnet *net, int32_t T) {
     return GRL_OK;
 }
 
+// Debug / profiling: attach a timestamp buffer to the persistent rollout and read the stage clock of workgroup 0 after the next
+// rollout (100 MHz constant clock ticks at every barrier of the kernel).  n_out = number of stamps written to out[0..max).
+int grl_fnet_rollout_stage_times(grl_fnet *net, int64_t *out, int32_t max, int32_t *n_out) {
+    if (!net || !n_out) return GRL_E_INVALID;
+    hipSetDevice(net->h->cfg.device_id);
+    if (!net->d_ts) {
+        int rc = falloc(net, &net->d_ts, 4096);
+        if (rc == GRL_OK) rc = falloc(net, &net->d_ts_n, 4);
+        *n_out = 0;
+        return rc;
+    }
+    FNET_HIP(net, hipStreamSynchronize(net->h->stream));
+    int n = 0;
+    FNET_HIP(net, hipMemcpy(&n, net->d_ts_n, sizeof(int), hipMemcpyDeviceToHost));
+    if (n > max) n = max;
+    if (out && n > 0) FNET_HIP(net, hipMemcpy(out, net->d_ts, (size_t)n * sizeof(long long), hipMemcpyDeviceToHost));
+    *n_out = n;
+    return GRL_OK;
+}
+
 int grl_fnet_train_rollout(grl_fnet *net, float lr, float *stats_host) {
     if (!net || !net->ro_states || net->T <= 0) return ffail(net, GRL_E_STATE, "grl_fnet_train_rollout: no rollout to train on");
     hipSetDevice(net->h->cfg.device_id);
     const int n = net->T * net->h->E;
-    if (net->h->cfg.env_kind == GRL_ENV_SOLOW)
-        return train_device(net, n, net->ro_states, net->ro_hist, net->ro_act, net->ro_adv, net->ro_y, lr, 1, stats_host);
     return train_device(net, n, net->ro_states, nullptr, net->ro_act, net->ro_adv, net->ro_y, lr, 1, stats_host, net->ro_nhist);
 }
 
@@ -660,9 +698,7 @@ int grl_fnet_train_rollout_grads(grl_fnet *net, float *stats_host) {
     if (!net || !net->ro_states || net->T <= 0) return ffail(net, GRL_E_STATE, "grl_fnet_train_rollout_grads: no rollout to train on");
     hipSetDevice(net->h->cfg.device_id);
     const int n = net->T * net->h->E;
-    int rc = net->h->cfg.env_kind == GRL_ENV_SOLOW
-                 ? train_grads_device(net, n, net->ro_states, net->ro_hist, net->ro_act, net->ro_adv, net->ro_y)
-                 : train_grads_device(net, n, net->ro_states, nullptr, net->ro_act, net->ro_adv, net->ro_y, net->ro_nhist);
+    int rc = train_grads_device(net, n, net->ro_states, nullptr, net->ro_act, net->ro_adv, net->ro_y, net->ro_nhist);
     if (rc) return rc;
     return train_apply_device(net, 0.f, 0, 1.0f, stats_host);
 }

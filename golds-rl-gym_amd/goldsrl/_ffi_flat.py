@@ -40,6 +40,7 @@ FNET_SIGNATURES = {
     "grl_fnet_comm_broadcast_params": (C.c_int, [_P, _I]),
     "grl_fnet_comm_destroy": (C.c_int, [_P]),
     "grl_fnet_comm_info": (C.c_int, [_P, _P, _P, _P, _P, _P]),
+    "grl_fnet_rollout_stage_times": (C.c_int, [_P, _P, _I, _P]),
     "grl_comm_unique_id_bytes": (C.c_size_t, []),
     "grl_comm_unique_id": (C.c_int, [_P, _SZ]),
 }
@@ -214,6 +215,13 @@ class FlatNet(object):
 
     def comm_broadcast_params(self, root=0):
         self._check(self.lib.grl_fnet_comm_broadcast_params(self.n, root))
+
+    def rollout_stage_times(self):
+        """Constant-clock ticks (10 ns) of workgroup 0 at every barrier of the last persistent rollout (first call: attaches)."""
+        buf = np.zeros(4096, np.int64)
+        n = C.c_int32()
+        self._check(self.lib.grl_fnet_rollout_stage_times(self.n, _ffi._ptr(buf), 4096, C.byref(n)))
+        return buf[:n.value].copy()
 
     def comm_info(self):
         """What RCCL reports for the attached communicator (ranks = ncclCommCount, 0 without one) and the all-reduce timing."""

@@ -83,6 +83,9 @@ int grl_fnet_apply_grads(grl_fnet *net, float lr, float grad_scale, float *stats
 /* "actions" (T,E,A) "values" (T,E) "rewards" (T,E) raw "masks" (T,E) "y" (T,E) "adv" (T,E) "boot" (E,)
  * "states" (T,E,S0); Solow: "histories" (T,E,rnn,2); TradeAR1: "nhist" (T,E) int32 rows of the window */
 int grl_fnet_read_rollout(grl_fnet *net, const char *which, void *host, size_t bytes);
+/* Profiling aid for the persistent rollout kernel: the first call attaches a timestamp buffer (n_out = 0); after the next
+ * grl_fnet_rollout a call returns the constant-clock (100 MHz) ticks workgroup 0 took at every barrier of the kernel. */
+int grl_fnet_rollout_stage_times(grl_fnet *net, int64_t *out, int32_t max, int32_t *n_out);
 
 /* ---- multi-GPU (BASELINE config 5: 65 536 TradeAR1 envs over 8 GPUs): one process per GPU owning a contiguous env block, one
  * RCCL all-reduce (sum, fp32, ~31k floats: latency-bound) of the flat gradient per rollout; no counterpart in the reference

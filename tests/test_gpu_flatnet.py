@@ -259,3 +259,42 @@ def test_persistent_rollout_is_bit_identical_to_the_graph_of_launches(kind, E, c
         assert np.array_equal(pa[k], pb[k])
     if cap < 20:      # episodes ended inside the rollouts: resets, tape refills and R6 records were exercised
         assert sum(len(d["recs"]) for d in a) >= 2 * E
+
+
+@pytest.mark.parametrize("kind", ["solow", "trade"])
+def test_fast_forward_form_equals_the_layer_by_layer_form(kind, monkeypatch):
+    """net_flat_fast.inc (2T + 5 stages: input halves of the GRU GEMMs hoisted out of the time loop, fused epilogues, merged
+    heads) against the layer-by-layer forward it replaces for synthesized windows (GRL_FLAT_FORWARD=layers).  Solow (D = 2,
+    even): the same MFMA chains, bit for bit, forward values AND gradients; TradeAR1 (D = 33): the x / h split moves one
+    product between two MFMA instructions -- agreement to float32 rounding."""
+    from goldsrl import _ffi
+    from goldsrl import rollout as R
+    res = {}
+    for mode in ("fast", "layers"):
+        if mode == "layers":
+            monkeypatch.setenv("GRL_FLAT_FORWARD", "layers")
+        else:
+            monkeypatch.delenv("GRL_FLAT_FORWARD", raising=False)
+        monkeypatch.setenv("GRL_FLAT_ROLLOUT", "graph")      # the graph rollout goes through launch_forward in both modes
+        E, T = 300, 6
+        if kind == "solow":
+            eng = _ffi.Engine(_ffi.ENV_SOLOW, E, seed=4, max_episode_steps=4)
+        else:
+            eng = _ffi.Engine(_ffi.ENV_TRADE, E, seed=4, n_assets=16, rnn_length=20, max_episode_steps=4)
+        eng.reset()
+        roll = R.FlatPolicyRollout(eng, T, train=False)
+        pred = roll.net.predict_env()
+        roll.run(); eng.wait()
+        vals = roll.net.read_rollout("values", (T, E))
+        roll.net.train_rollout_grads()
+        res[mode] = (pred, vals, roll.net.get_grads())
+        roll.net.close(); eng.close()
+    (pf, vf, gf), (pl, vl, gl) = res["fast"], res["layers"]
+    if kind == "solow":
+        for k in pf:
+            assert np.array_equal(pf[k], pl[k]), k
+        assert np.array_equal(vf, vl) and np.array_equal(gf, gl)
+    else:
+        for k in pf:
+            np.testing.assert_allclose(pf[k], pl[k], rtol=2e-6, atol=2e-6)
+        np.testing.assert_allclose(gf, gl, rtol=1e-4, atol=1e-7 * np.abs(gl).max() + 1e-9)

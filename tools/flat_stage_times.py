@@ -1,0 +1,35 @@
+"""Stage clock of the persistent flat rollout: where one workgroup's time goes (workgroup 0, 100 MHz constant clock)."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "golds-rl-gym_amd"))
+from goldsrl import _ffi  # noqa: E402
+from goldsrl import rollout as R  # noqa: E402
+
+kind, E = (sys.argv[1], int(sys.argv[2])) if len(sys.argv) > 2 else ("solow", 4096)
+T = 20
+if kind == "solow":
+    eng = _ffi.Engine(_ffi.ENV_SOLOW, E, seed=1692)
+else:
+    eng = _ffi.Engine(_ffi.ENV_TRADE, E, seed=1692, n_assets=16, rnn_length=20)
+eng.reset()
+roll = R.FlatPolicyRollout(eng, T, train=False)
+roll.run(); eng.wait()
+roll.net.rollout_stage_times()
+roll.run(); eng.wait()
+ts = roll.net.rollout_stage_times().astype(np.float64) * 0.01      # us
+d = np.diff(ts)
+rnn = roll.net.cfg.rnn_length
+per_fwd = 2 * rnn + 6          # stamps inside one forward (entry + P0 + 2 per GRU step + DT + H1 + H2 + H3)
+print("stamps", len(ts), "total us", ts[-1] - ts[0])
+# layout: [start], then per step: [before fwd], fwd stamps..., [after sample], [after env], [after prices/tape]
+i = 1
+for t in range(2):
+    seg = d[i:i + per_fwd + 3 + 1]
+    print("step", t, "record->fwd0 %.2f" % seg[0], "fwd stages:", np.round(seg[1:per_fwd + 1], 2).tolist(),
+          "sample %.2f env %.2f post %.2f" % tuple(seg[per_fwd + 1:per_fwd + 4]))
+    i += per_fwd + 4
+print("forward total per step (us):", float(np.sum(d[2:2 + per_fwd])))
