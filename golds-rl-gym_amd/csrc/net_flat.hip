@@ -13,6 +13,7 @@
 #include <string.h>
 
 #include <cmath>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -80,6 +81,8 @@ struct FlatArgs {
     float inv_n;
     float *slab;                    // [blocks][o.total]
     double *stats64;
+    long long *ts;                  // stage clock of workgroup 0 (debug, grl_fnet_rollout_stage_times) or nullptr
+    int *ts_n;
 };
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -184,6 +187,7 @@ struct grl_fnet {
     int ro_persistent;             // 1: the T-step actor loop is ONE persistent kernel (net_flat_rollout.inc); 0: the hipGraph of launches
     size_t ro_lds_set;             // dynamic LDS size the rollout kernel's attribute is set to
     void *d_roargs;                // RolloutArgs of the persistent rollout, in device memory
+    int arg_slot;                  // this net's slot of g_flat_args (net_flat_fast.inc), -1: none free (graph path)
     long long *d_ts;               // stage timestamps of workgroup 0 of the persistent rollout (debug: grl_fnet_rollout_stage_times)
     int *d_ts_n;
     int last_n;                    // samples of the last gradient pass (grl_fnet_apply_grads normalises the loss sums with it)
@@ -223,6 +227,7 @@ static FlatArgs base_args(grl_fnet *net, int n, const float *states, const float
     a.P = net->params; a.o = net->off; a.n = n; a.S0 = net->cfg.static_size; a.D = net->cfg.temporal_size; a.T = net->cfg.rnn_length;
     a.A = net->cfg.num_actions; a.scale = net->cfg.scale; a.bound = net->cfg.mu_bound; a.states = states; a.hist = hist;
     a.mu = mu; a.sigma = sigma; a.vs = vs; a.ws = save ? net->ws : nullptr; a.nhist = nhist;
+    a.ts = net->d_ts; a.ts_n = net->d_ts_n;
     return a;
 }
 
@@ -363,12 +368,28 @@ static int enqueue_rollout(grl_fnet *net, int T) {
 
 // the T-step actor loop as ONE kernel: a workgroup owns 64 envs for the whole rollout (net_flat_rollout.inc).  Returns
 // GRL_E_SIZE when the rollout's LDS footprint does not fit a CU (the caller then takes the graph path).
+// slots of g_flat_args: one per live net of the process (a net that finds none free keeps the graph path)
+static std::mutex g_slot_mu;
+static bool g_slot_used[kFlatArgSlots];
+static int flat_slot_take() {
+    std::lock_guard<std::mutex> lk(g_slot_mu);
+    for (int i = 0; i < kFlatArgSlots; ++i)
+        if (!g_slot_used[i]) { g_slot_used[i] = true; return i; }
+    return -1;
+}
+static void flat_slot_release(int i) {
+    if (i < 0) return;
+    std::lock_guard<std::mutex> lk(g_slot_mu);
+    g_slot_used[i] = false;
+}
+
 static int launch_persistent_rollout(grl_fnet *net, int T) {
     grl_handle *h = net->h;
+    if (net->arg_slot < 0) return GRL_E_SIZE;
     const bool solow = h->cfg.env_kind == GRL_ENV_SOLOW;
     RolloutArgs R{};
     R.f = base_args(net, h->E, nullptr, nullptr, nullptr, nullptr, nullptr, false);
-    R.steps = T; R.env_kind = h->cfg.env_kind;
+    R.steps = T; R.env_kind = h->cfg.env_kind; R.slot = net->arg_slot;
     const int n_assets = solow ? 0 : h->cfg.n_assets;
     const size_t lds_bytes = (size_t)rollout_lds_floats(net->cfg.static_size, T, n_assets, &R) * sizeof(float);
     if (lds_bytes > 160 * 1024) return GRL_E_SIZE;
@@ -403,7 +424,10 @@ static int launch_persistent_rollout(grl_fnet *net, int T) {
         net->allocs.push_back(net->d_roargs);
     }
     FNET_HIP(net, hipMemcpyAsync(net->d_roargs, &R, sizeof(RolloutArgs), hipMemcpyHostToDevice, st));      // pageable source: staged before the call returns
-    hipLaunchKernelGGL(flat_rollout_kernel, dim3((h->E + 63) / 64), dim3(FNT), lds_bytes, st, R.f, (const RolloutArgs *)net->d_roargs);
+    FNET_HIP(net, hipMemcpyToSymbolAsync(HIP_SYMBOL(g_flat_args), &R.f, sizeof(FlatArgs), (size_t)net->arg_slot * sizeof(FlatArgs),
+                                         hipMemcpyHostToDevice, st));
+    (void)hipGetLastError();      // the symbol lookup may probe other ordinals and leave a stale error on this thread
+    hipLaunchKernelGGL(flat_rollout_kernel, dim3((h->E + 63) / 64), dim3(FNT), lds_bytes, st, (const RolloutArgs *)net->d_roargs);
     FNET_HIP(net, hipGetLastError());
     return GRL_OK;
 }
@@ -454,6 +478,7 @@ int grl_fnet_create(grl_handle *h, const grl_fnet_config *cfg, grl_fnet **out) {
         const char *e = getenv("GRL_FLAT_ROLLOUT");
         n->ro_persistent = (e && strcmp(e, "graph") == 0) ? 0 : 1;
         n->ro_lds_set = 0; n->d_ts = nullptr; n->d_ts_n = nullptr; n->d_roargs = nullptr;
+        n->arg_slot = flat_slot_take();
         const char *f = getenv("GRL_FLAT_FORWARD");
         n->fast_forward = (f && strcmp(f, "layers") == 0) ? 0 : 1;
     }
@@ -488,6 +513,7 @@ int grl_fnet_destroy(grl_fnet *n) {
         (void)hipGetLastError();   // RCCL teardown may leave a stale HIP error on this thread
     }
     if (n->ar_ev0) { hipEventDestroy(n->ar_ev0); hipEventDestroy(n->ar_ev1); }
+    flat_slot_release(n->arg_slot);
     for (void *p : n->allocs) hipFree(p);
     delete n;
     return GRL_OK;

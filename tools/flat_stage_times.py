@@ -10,6 +10,9 @@ from goldsrl import _ffi  # noqa: E402
 from goldsrl import rollout as R  # noqa: E402
 
 kind, E = (sys.argv[1], int(sys.argv[2])) if len(sys.argv) > 2 else ("solow", 4096)
+graph = len(sys.argv) > 3 and sys.argv[3] == "graph"
+if graph:
+    os.environ["GRL_FLAT_ROLLOUT"] = "graph"
 T = 20
 if kind == "solow":
     eng = _ffi.Engine(_ffi.ENV_SOLOW, E, seed=1692)
@@ -17,14 +20,20 @@ else:
     eng = _ffi.Engine(_ffi.ENV_TRADE, E, seed=1692, n_assets=16, rnn_length=20)
 eng.reset()
 roll = R.FlatPolicyRollout(eng, T, train=False)
+roll.net.rollout_stage_times()      # attach before the first rollout (the graph path captures its kernel arguments then)
 roll.run(); eng.wait()
-roll.net.rollout_stage_times()
-roll.run(); eng.wait()
+if not graph:
+    roll.run(); eng.wait()
 ts = roll.net.rollout_stage_times().astype(np.float64) * 0.01      # us
 d = np.diff(ts)
 rnn = roll.net.cfg.rnn_length
 per_fwd = 2 * rnn + 6          # stamps inside one forward (entry + P0 + 2 per GRU step + DT + H1 + H2 + H3)
 print("stamps", len(ts), "total us", ts[-1] - ts[0])
+if graph:      # the forward kernel alone: only the LAST launch's stamps survive a rollout? no: the counter runs on; show one forward
+    per = 2 * rnn + 7
+    k = per * 3
+    print("standalone forward stages (us):", np.round(d[k:k + per - 1], 2).tolist(), "sum %.2f" % float(np.sum(d[k:k + per - 1])))
+    sys.exit(0)
 # layout: [start], then per step: [before fwd], fwd stamps..., [after sample], [after env], [after prices/tape]
 i = 1
 for t in range(2):
