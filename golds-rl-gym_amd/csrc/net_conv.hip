@@ -724,7 +724,7 @@ int grl_net_create(grl_handle *h, const grl_net_config *cfg, grl_net **out) {
         n->expand2_gemm = (e2 && strcmp(e2, "lds") == 0) ? 0 : 1;
     }
     n->pslice_rows = PATCH_SLICE_ROWS; n->pwgrad_xcd = 2;
-    if (const char *e = getenv("GRL_PATCH_SLICE")) { const int v = atoi(e); if (v == 256 || v == 512 || v == 1024 || v == 2048) n->pslice_rows = v; }
+    if (const char *e = getenv("GRL_PATCH_SLICE")) { const int v = atoi(e); if (v == 256 || v == 512 || v == 1024 || v == 2048 || v == 4096 || v == 8192) n->pslice_rows = v; }
     if (const char *e = getenv("GRL_PATCH_WGRAD_XCD")) n->pwgrad_xcd = atoi(e);
     n->pdgrad_xcd = 1;      // M tile per XCD (A fetched once): 40.6 -> 38.5 ms per update at 81 920-sample chunks; spread (0) was faster at 40 960
     n->tn_wgs = 1024; n->tn_wgs_dense = 512;
