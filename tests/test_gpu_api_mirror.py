@@ -153,7 +153,7 @@ def test_grid_runners_drop_in_protocol_swarm():
     for i in range(E):
         lb, ab, pos = O.swarm_observe_compact(ox[i], oxa[i], G)
         assert np.array_equal(positions[i], pos)
-        np.testing.assert_array_equal(states[i], O.swarm_local_states(O.swarm_grid_from_compact(lb, ab, G), pos).astype(np.float32))
+        np.testing.assert_array_equal(states[i], O.swarm_local_states(O.swarm_grid_from_compact(lb, ab, G), pos))      # float64 slot, exact
     assert not overs.any()
 
 

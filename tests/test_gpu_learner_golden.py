@@ -148,3 +148,42 @@ def test_grid_learner_loop_replayed_on_the_device(golden):
     np.testing.assert_allclose(tot, g["grid_running_total"], rtol=2e-6)
     assert np.array_equal(steps, g["grid_running_steps"])
     eng.close()
+
+
+def test_grid_runners_slots_incl_history_against_swarm_runner(golden):
+    """The drop-in GridRunners (goldsrl.agents.paac.runners) over SEEDED facade envs against SwarmRunner._run itself with
+    rnn_length 2: STATE, HISTORY (the worker's window as it behaves: copies of the current state, int-truncated while short),
+    POSITIONS, REWARD, DONE of every step incl. the TimeLimit reset, which replays the reference's seed-192 episode."""
+    from goldsrl.agents.paac.emulator_runner import SwarmRunner
+    from goldsrl.agents.paac.runners import GridRunners
+    from goldsrl.agents.state_processors import SwarmStateProcessor
+    from goldsrl.envs.multiagent import SwarmEnv
+    g = golden("swarm_runner")
+    rnn, k = 2, "r2_"
+    acts = g[k + "act"]
+    steps, E = acts.shape[:2]
+    emulators = np.asarray([SwarmEnv(seed=192, max_episode_steps=4) for _ in range(E)])
+    sp = SwarmStateProcessor(grid_size=84)
+    init, idxs = [], []
+    for em in emulators:                            # paac.py:245-251
+        s = sp.process_state(em.reset())
+        init.append(SwarmRunner.get_local_states(s, sp.positions)); idxs.append(sp.positions)
+    init = np.array(init)
+    assert np.array_equal(init, _dense(g[k + "init_states_idx"], g[k + "init_states_val"], (E, 10, 84, 84, 3)))
+    hist0 = np.zeros((E, 10, rnn, 84, 84, 3), np.float32); hist0[:, :, 0] = init
+    variables = [init, hist0, np.array(idxs), np.zeros((E, 10), np.float32), np.zeros((E, 10), np.float32), np.zeros((E, 10, 2), np.float32)]
+    runners = GridRunners(emulators, 2, variables, SwarmRunner, None, 84)
+    states, hists, positions, rewards, overs, actions = runners.get_shared_variables()
+    ref_states = _dense(g[k + "states_idx"], g[k + "states_val"], g[k + "states_shape"])
+    ref_hist = _dense(g[k + "hist_idx"], g[k + "hist_val"], g[k + "hist_shape"])
+    for t in range(steps):
+        for i in range(E):
+            actions[i] = acts[t][i]                 # in place, as paac.py:313-314
+        runners.update_environments(); runners.wait_updated()
+        assert np.array_equal(states, ref_states[t])
+        assert np.array_equal(hists, ref_hist[t].astype(np.float32))
+        assert np.array_equal(positions, g[k + "pos"][t])
+        np.testing.assert_allclose(rewards, g[k + "rew"][t], rtol=1e-6)
+        assert np.array_equal(overs, g[k + "done"][t])
+    assert overs.sum() == 0 and g[k + "done"][3].all()
+    runners.stop()
