@@ -220,10 +220,11 @@ def spread(per_s):
 
 def flat_config_block(kind, E, T, device_id, steps=10):
     """BASELINE configs[1] (Solow-v0, 4 096 envs) / the per-GPU share of configs[4] (TradeAR1 n=16, 65 536 envs / 8 GPUs = 8 192)
-    with FlatPolicyVNetwork (GRU(32) + MLP): device-resident T-step PAAC rollout (one hipGraph) + gradient step, timed here so the
-    numbers are driver-visible.  These shapes are LAUNCH/LATENCY bound: a step moves E x 53 B (Solow) / E x 481 B
-    (TradeAR1-16) of env state and ~45 kMAC per sample through ~40 dependent stages; a bandwidth fraction would be meaningless, so
-    the block states the per-update time, the number of dependent launches and the bytes for scale."""
+    with FlatPolicyVNetwork (GRU(32) + MLP): the T-step PAAC rollout as ONE persistent kernel (a workgroup keeps 64 envs for all
+    T steps: forward, sample, env step, auto-reset, bookkeeping, returns -- csrc/net_flat_rollout.inc) + the gradient step, timed
+    here so the numbers are driver-visible.  These shapes are LATENCY bound: a step moves E x 53 B (Solow) / E x 481 B
+    (TradeAR1-16) of env state and ~45 kMAC per sample through 2 x rnn + 5 dependent stages of one workgroup per CU; a bandwidth
+    fraction would be meaningless, so the block states the per-update time, the number of dependent launches and the bytes."""
     from goldsrl import _ffi
     from goldsrl import rollout as R
     if kind == "solow":
@@ -243,7 +244,10 @@ def flat_config_block(kind, E, T, device_id, steps=10):
         out["ms_per_update" if train else "ms_per_rollout"] = dt * 1e3
     out.update({"unit": "env-steps/s", "steps": steps, "dtype": "f32",
                 "bound": "launch/latency",
-                "dependent_launches_per_update": T * 4 + 2 + 6,      # T x (forward, sample, env step, mask) in one graph + bootstrap/returns + fwd/bwd/reduce/norm/finalize/adam
+                # rollout: done-count memset + argument upload x2 + ONE kernel; update: forward, two memsets, backward, slab reduce,
+                # sum of squares, finalize, Adam
+                "dependent_launches_per_update": 4 + 8,
+                "rollout_kernel": "flat_rollout_kernel (persistent: one workgroup of 16 waves per 64 envs for all T steps)",
                 "env_bytes_per_update": E * T * bytes_per_env_step,
                 "note": "value = rollout + loss/backward/clip/Adam; %d KB of env traffic per step against ~%d us per step: not "
                         "bandwidth bound at this size" % (E * bytes_per_env_step // 1024, int(out["ms_per_rollout"] * 1e3 / (T + 1)))})
