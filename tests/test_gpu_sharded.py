@@ -178,3 +178,31 @@ def test_flat_net_rccl_communicator_world_size_1():
     assert not np.array_equal(p0, net.get_params())
     net.comm_destroy()
     net.close(); eng.close()
+
+
+@pytest.mark.timeout(900)
+def test_bench_under_the_elastic_launcher_two_ranks_on_one_gpu():
+    """The driver's N > 1 launch line, rehearsed with two ranks on device 0: `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P bench.py --gpus 2 ...`.  The launcher owns MASTER_PORT; the ranks
+    (which never import it) meet over goldsrl.distributed's own store, try RCCL (refused: two ranks on one device), fall back
+    TOGETHER to the host exchange, and rank 0 prints one line with the communicator facts."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, GRL_BENCH_FORCE_DEVICE="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "GRL_RDZV_KEY", "GRL_STORE_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--envs", "256", "--steps", "2",
+                        "--warmup", "1", "--no-cpu-baseline", "--no-strong"], env=env, capture_output=True, text=True, timeout=800)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["envs_total"] == 512 and j["value"] > 0
+    assert j["gradient_exchange"] in ("rccl", "host-store-fallback")
+    assert j["comm"]["params_equal_across_ranks"] is True
+    if j["gradient_exchange"] == "rccl":
+        assert j["rccl_ranks"] == 2 and len(j["allreduce_ms"]) == 2 and all(m > 0 for m in j["allreduce_ms"])
+    else:
+        assert j["rccl_ranks"] == 0
+    assert "ms_per_step_spread" in j and j["ms_per_step_spread"]["n"] == 2
