@@ -892,8 +892,19 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void gemm_tn(AG ag, 
     ag.tap(i0, toff, ty, tx);   // the BM-wide column run lies inside one tap row (checked on the host)
 
     // this thread's part of a tile: rows NA*(tid/A4) .. +NA-1 (A), NB*(tid/B4) .. +NB-1 (B), columns 4*ca .. 4*ca+3 / 4*cb ..
-    const int ca = tid % A4, ma = NA * (tid / A4);
-    const int cb = tid % B4, mb = NB * (tid / B4);
+    // LDS has 32 banks of 4 bytes: a store instruction is served 128 bytes (32 x 4-byte or 16 x 8-byte lanes) per pass.  With the
+    // plain map (row group = tid / A4) the lanes of one pass share a row group, i.e. one 8-byte half (NA = 4) or one dword pair
+    // (NA = 2) of their 16-byte chunk, and columns c, c + 2 meet in the same bank: a 2-way conflict on every staging store
+    // (SQ_LDS_BANK_CONFLICT 4-6 % of the wave cycles of every gemm_tn instance, round 2).  Flipping the row group's half / pair by
+    // bit 1 of the column index spreads a pass over all 32 banks; which (row, column) elements a thread carries changes, where
+    // they land in LDS does not.
+    const int ca = tid % A4, cb = tid % B4;
+    int ga = tid / A4, gb = tid / B4;
+    if (NA == 4) ga ^= (ca >> 1) & 1;
+    if (NA == 2) ga ^= ((ca >> 1) & 1) << 1;
+    if (NB == 4) gb ^= (cb >> 1) & 1;
+    if (NB == 2) gb ^= ((cb >> 1) & 1) << 1;
+    const int ma = NA * ga, mb = NB * gb;
     float4 ra[NA], rb[NB];
     unsigned vma = 0, vmb = 0;
     // physical rows of the tile about to be loaded (-1: past the range / padding).  They are fetched one tile ahead of
