@@ -89,6 +89,7 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 
 #include "net_flat_mfma.inc"
 #include "net_flat_fast.inc"
+#include "net_flat_bwd_fast.inc"
 #include "net_flat_rollout.inc"
 
 __global__ void flat_slab_reduce_kernel(const float *__restrict__ slab, int blocks, long n, float *__restrict__ dst) {
@@ -259,12 +260,22 @@ static int train_grads_device(grl_fnet *net, int n, const float *states, const f
     int rc = launch_forward(net, n, states, hist, net->mu, net->sigma, net->vs, true, nhist);
     if (rc) return rc;
     int groups = (n + 63) / 64;
+    const bool fast = nhist && net->cfg.static_size == net->cfg.temporal_size && net->fast_forward && net->arg_slot >= 0;
     int blocks = groups < net->slab_blocks ? groups : net->slab_blocks;
+    if (fast && blocks > 256) blocks = 256;      // the 16-wave form: one workgroup per CU (100 KB of LDS)
     FNET_HIP(net, hipMemsetAsync(net->slab, 0, (size_t)blocks * net->off.total * 4, st));
     FNET_HIP(net, hipMemsetAsync(net->stats64, 0, 4 * sizeof(double), st));
     FlatArgs a = base_args(net, n, states, hist, net->mu, net->sigma, net->vs, true, nhist);
     a.actions = actions; a.adv = adv; a.y = y; a.inv_n = 1.0f / (float)n; a.slab = net->slab; a.stats64 = net->stats64;
-    hipLaunchKernelGGL(flat_backward_kernel, dim3(blocks), dim3(256), FLAT_LDS_BYTES, st, a);
+    if (fast && net->arg_slot >= 0) {
+        // the stages of the fast backward are calls that read their arguments from the net's __constant__ slot (net_flat_fast.inc)
+        FNET_HIP(net, hipMemcpyToSymbolAsync(HIP_SYMBOL(g_flat_args), &a, sizeof(FlatArgs), (size_t)net->arg_slot * sizeof(FlatArgs),
+                                             hipMemcpyHostToDevice, st));
+        (void)hipGetLastError();
+        hipLaunchKernelGGL(flat_backward_fast_kernel, dim3(blocks), dim3(FNT), FB2_LDS_BYTES, st, net->arg_slot, n, net->cfg.rnn_length, a.ts, a.ts_n);
+    } else {
+        hipLaunchKernelGGL(flat_backward_kernel, dim3(blocks), dim3(256), FLAT_LDS_BYTES, st, a);
+    }
     hipLaunchKernelGGL(flat_slab_reduce_kernel, dim3((unsigned)((net->off.total + 255) / 256)), dim3(256), 0, st, net->slab, blocks,
                        net->off.total, net->grads);
     FNET_HIP(net, hipGetLastError());
@@ -493,6 +504,8 @@ int grl_fnet_create(grl_handle *h, const grl_fnet_config *cfg, grl_fnet **out) {
         e = hipFuncSetAttribute((const void *)flat_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLAT_LDS_BYTES);
     if (rc == GRL_OK && e == hipSuccess)
         e = hipFuncSetAttribute((const void *)flat_forward_fast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ff_lds_bytes(MAXS0));
+    if (rc == GRL_OK && e == hipSuccess)
+        e = hipFuncSetAttribute((const void *)flat_backward_fast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FB2_LDS_BYTES);
     if (rc == GRL_OK && e != hipSuccess) rc = ffail(n, GRL_E_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
     if (rc != GRL_OK) {
         fail(h, rc, "grl_fnet_create: " + n->err);

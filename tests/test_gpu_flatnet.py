@@ -264,9 +264,10 @@ def test_persistent_rollout_is_bit_identical_to_the_graph_of_launches(kind, E, c
 @pytest.mark.parametrize("kind", ["solow", "trade"])
 def test_fast_forward_form_equals_the_layer_by_layer_form(kind, monkeypatch):
     """net_flat_fast.inc (2T + 5 stages: input halves of the GRU GEMMs hoisted out of the time loop, fused epilogues, merged
-    heads) against the layer-by-layer forward it replaces for synthesized windows (GRL_FLAT_FORWARD=layers).  Solow (D = 2,
-    even): the same MFMA chains, bit for bit, forward values AND gradients; TradeAR1 (D = 33): the x / h split moves one
-    product between two MFMA instructions -- agreement to float32 rounding."""
+    heads) and its backward twin (net_flat_bwd_fast.inc) against the layer-by-layer kernels they replace for synthesized windows
+    (GRL_FLAT_FORWARD=layers).  Forward: Solow (D = 2, even) runs the same MFMA chains, bit for bit; TradeAR1 (D = 33): the x / h
+    split moves one product between two MFMA instructions -- agreement to float32 rounding.  Gradients: the fast backward sums in
+    another order (16 x 16 x 4 tiles; the GRU kernels' input rows from the dz summed over time): float32 rounding."""
     from goldsrl import _ffi
     from goldsrl import rollout as R
     res = {}
@@ -293,8 +294,9 @@ def test_fast_forward_form_equals_the_layer_by_layer_form(kind, monkeypatch):
     if kind == "solow":
         for k in pf:
             assert np.array_equal(pf[k], pl[k]), k
-        assert np.array_equal(vf, vl) and np.array_equal(gf, gl)
+        assert np.array_equal(vf, vl)
+        np.testing.assert_allclose(gf, gl, rtol=1e-4, atol=1e-6 * np.abs(gl).max() + 1e-9)
     else:
         for k in pf:
             np.testing.assert_allclose(pf[k], pl[k], rtol=2e-6, atol=2e-6)
-        np.testing.assert_allclose(gf, gl, rtol=1e-4, atol=1e-7 * np.abs(gl).max() + 1e-9)
+        np.testing.assert_allclose(gf, gl, rtol=1e-4, atol=1e-6 * np.abs(gl).max() + 1e-9)

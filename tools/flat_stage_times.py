@@ -11,6 +11,7 @@ from goldsrl import rollout as R  # noqa: E402
 
 kind, E = (sys.argv[1], int(sys.argv[2])) if len(sys.argv) > 2 else ("solow", 4096)
 graph = len(sys.argv) > 3 and sys.argv[3] == "graph"
+bwd = len(sys.argv) > 3 and sys.argv[3] == "bwd"
 if graph:
     os.environ["GRL_FLAT_ROLLOUT"] = "graph"
 T = 20
@@ -20,6 +21,21 @@ else:
     eng = _ffi.Engine(_ffi.ENV_TRADE, E, seed=1692, n_assets=16, rnn_length=20)
 eng.reset()
 roll = R.FlatPolicyRollout(eng, T, train=False)
+if bwd:      # stage clock of the gradient step's backward kernel (workgroup 0, its first group)
+    roll.run(); eng.wait()
+    roll.net.rollout_stage_times()
+    roll.net.train_rollout_grads()
+    ts = roll.net.rollout_stage_times().astype(np.float64) * 0.01
+    rnn = roll.net.cfg.rnn_length
+    nf = 2 * rnn + 7                 # the training forward stamps first
+    d = np.diff(ts)
+    print("stamps", len(ts))
+    nb = 8 + 3 * rnn + 1             # per group: entry + St0..St5 boundaries + 3 per GRU step + end
+    k = None
+    # the forward kernel's workgroup 0 wrote nf stamps; then the backward's groups follow
+    seg = d[nf:nf + nb]
+    print("backward, first group, stages (us):", np.round(seg, 2).tolist(), "sum %.1f" % float(np.sum(seg)))
+    sys.exit(0)
 roll.net.rollout_stage_times()      # attach before the first rollout (the graph path captures its kernel arguments then)
 roll.run(); eng.wait()
 if not graph:
