@@ -956,6 +956,9 @@ static int read_activation_impl(grl_net *n, const char *which, float *host, size
     else if (w == "p1") { src = n->p1; per = 512; }
     else if (w == "v1") { src = n->v1; per = 512; }
     else if (w == "v2") { src = n->v2; per = 256; }
+    else if (w == "gp1") { src = n->gp1; per = 512; }
+    else if (w == "gv2") { src = n->gv2; per = 256; }
+    else if (w == "gd2") { src = n->gd2; per = 256; }
     else return nfail(n, GRL_E_INVALID, "grl_net_read_activation: unknown tensor '" + w + "'");
     size_t need = (size_t)n->last_n * per * 4;
     if (bytes != need) return nfail(n, GRL_E_SIZE, "grl_net_read_activation: need " + std::to_string(need) + " bytes");

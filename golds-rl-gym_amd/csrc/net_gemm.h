@@ -904,6 +904,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void gemm_tn(AG ag, 
     if (NA == 2) ga ^= ((ca >> 1) & 1) << 1;
     if (NB == 4) gb ^= (cb >> 1) & 1;
     if (NB == 2) gb ^= ((cb >> 1) & 1) << 1;
+    if (NB == 1) gb ^= ((cb >> 1) & 1) << 2;      // one row per thread, stored as (m, m+1) pairs after a lane exchange: see GRL_STORE_TILE
     const int ma = NA * ga, mb = NB * gb;
     float4 ra[NA], rb[NB];
     unsigned vma = 0, vmb = 0;
@@ -982,10 +983,24 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void gemm_tn(AG ag, 
             t4.x = v ? t4.x : 0.f; t4.y = v ? t4.y : 0.f; t4.z = v ? t4.z : 0.f; t4.w = v ? t4.w : 0.f;            \
             rb[i] = t4;                                                                                            \
         }                                                                                                          \
+        if (NB == 1) {      /* one row per thread: trade two columns with the thread holding the neighbouring row (same columns) */ \
+            const bool odd = gb & 1;                                                                               \
+            const float4 t4 = rb[0];                                                                               \
+            const float o0 = __shfl_xor(odd ? t4.x : t4.z, B4), o1 = __shfl_xor(odd ? t4.y : t4.w, B4);            \
+            unsigned h0, l0, h1, l1;                                                                               \
+            split2(odd ? o1 : t4.x, odd ? t4.w : o0, h0, l0);      /* even: column x rows (m, m+1); odd: column w rows (m-1, m) */ \
+            split2(odd ? o0 : t4.y, odd ? t4.z : o1, h1, l1);      /* even: column y; odd: column z */            \
+            const int q0 = GRL_TN_OFF((odd ? 3 : 0) * B4 + cb, mb & ~1), q1 = GRL_TN_OFF((odd ? 2 : 1) * B4 + cb, mb & ~1); \
+            *reinterpret_cast<unsigned *>(&Bs[0][q0]) = h0;                                                        \
+            *reinterpret_cast<unsigned *>(&Bs[1][q0]) = l0;                                                        \
+            *reinterpret_cast<unsigned *>(&Bs[0][q1]) = h1;                                                        \
+            *reinterpret_cast<unsigned *>(&Bs[1][q1]) = l1;                                                        \
+        } else {                                                                                                   \
         GRL_STORE_RUN(Bs, NB, GRL_TN_OFF(0 * B4 + cb, mb), rb, x)                                                  \
         GRL_STORE_RUN(Bs, NB, GRL_TN_OFF(1 * B4 + cb, mb), rb, y)                                                  \
         GRL_STORE_RUN(Bs, NB, GRL_TN_OFF(2 * B4 + cb, mb), rb, z)                                                  \
         GRL_STORE_RUN(Bs, NB, GRL_TN_OFF(3 * B4 + cb, mb), rb, w)                                                  \
+        }                                                                                                          \
     }
     f32x4 acc[TM][TN], acl[TM][TN];
 #pragma unroll
