@@ -231,9 +231,26 @@ enum {
     PT_ENV_WGRAD, PT_SLOT_FWD, PT_SLOT_DGRAD, PT_SLOT_WGRAD, PT_CLASS_CORR, PT_PER_AGENT, PT_COUNT
 };
 
+// Measurement aid (GRL_NET_EVICT=1, tools/mall_probe.sh): a 512 MiB write in front of a kernel, so that the kernel finds neither
+// its producer's output nor its weights in L2 / the 256 MB Infinity Cache.  Comparing a kernel's duration with and without it says
+// how much of its FETCH_SIZE the cache hierarchy behind L2 was serving.
+__global__ void evict_kernel(float4 *__restrict__ buf, size_t n4) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) buf[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+static void maybe_evict(grl_net *n) {
+    static const bool on = getenv("GRL_NET_EVICT") && atoi(getenv("GRL_NET_EVICT")) != 0;
+    if (!on) return;
+    static float4 *buf = nullptr;      // one per process: only ever written
+    constexpr size_t bytes = (size_t)512 << 20;
+    if (!buf && hipMalloc((void **)&buf, bytes) != hipSuccess) { buf = nullptr; return; }
+    hipLaunchKernelGGL(evict_kernel, dim3(2048), dim3(256), 0, n->h->stream, buf, bytes / 16);
+}
+
 struct GemmTimer {
     grl_net *n;
     GemmTimer(grl_net *net, double flops) : n(net) {
+        maybe_evict(n);
         if (n->prof_on && n->prof_used + 2 <= n->prof_ev.size()) {
             (void)hipEventRecord(n->prof_ev[n->prof_used], n->h->stream);
             n->prof_flops += flops;
