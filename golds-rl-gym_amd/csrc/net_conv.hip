@@ -117,6 +117,9 @@ struct grl_net : NetLane {
     float *w3t, *w2t;          // rearranged conv weights for the data gradients
     float *w3f;                // w3f[(tap,co)][ci] = W3[tap][ci][co] (slot product GEMM of conv3's forward)
     int shared_trunk;
+    // GEMM arithmetic: 0 = three fp16 products (operands must stay inside the fp16 range), 1 = v_mfma_f32_16x16x4_f32 (no range
+    // limit, ~5x the matrix-pipe time).  A pass that raised the range flag switches the net to 1 (range_fallback below).
+    int gemm_f32, range_fallback_on, range_fallbacks, range_bits_last, update_skipped_last;
     int loss_scale_on;         // per-pass power-of-two scale of the head gradients (net_train.inc); GRL_NET_LOSS_SCALE=off disables it
     int expand2_gemm, ctiles;  // conv2's per-agent corrections as a class-sorted GEMM (default) or the LDS-resident kernel (GRL_NET_EXPAND2=lds)
     float *w2corr;             // [4 classes][576][128] kernel slices of that GEMM, rebuilt with the transposes
@@ -230,6 +233,20 @@ enum {
     PT_OTHER = 0, PT_DENSE_FWD, PT_DENSE_DGRAD, PT_DENSE_WGRAD, PT_PATCH_FWD, PT_PATCH_DGRAD, PT_PATCH_WGRAD, PT_ENV_FWD, PT_ENV_DGRAD,
     PT_ENV_WGRAD, PT_SLOT_FWD, PT_SLOT_DGRAD, PT_SLOT_WGRAD, PT_CLASS_CORR, PT_PER_AGENT, PT_COUNT
 };
+
+// every GEMM launch goes through these two: the net's arithmetic form picks the instantiation
+template <int BM, int BN, int WGM, int WGN, class AG, class Epi, bool XCD = true, bool FENCE = true>
+static void launch_rowk(grl_net *net, dim3 grid, hipStream_t st, AG ag, const float *Bt, int ldb, int N, Epi epi) {
+    if (net->gemm_f32)
+        hipLaunchKernelGGL((gemm_rowk<BM, BN, WGM, WGN, AG, Epi, XCD, FENCE, true>), grid, dim3(64 * WGM * WGN), 0, st, ag, Bt, ldb, N, epi);
+    else
+        hipLaunchKernelGGL((gemm_rowk<BM, BN, WGM, WGN, AG, Epi, XCD, FENCE, false>), grid, dim3(64 * WGM * WGN), 0, st, ag, Bt, ldb, N, epi);
+}
+template <int BM, int BN, int WGM, int WGN, class AG, int XCD = 1>
+static void launch_tn(grl_net *net, dim3 grid, hipStream_t st, AG ag, const float *dY, int J, int mc, float *slab) {
+    if (net->gemm_f32) hipLaunchKernelGGL((gemm_tn<BM, BN, WGM, WGN, AG, XCD, true>), grid, dim3(64 * WGM * WGN), 0, st, ag, dY, J, mc, slab);
+    else hipLaunchKernelGGL((gemm_tn<BM, BN, WGM, WGN, AG, XCD, false>), grid, dim3(64 * WGM * WGN), 0, st, ag, dY, J, mc, slab);
+}
 
 // Measurement aid (GRL_NET_EVICT=1, tools/mall_probe.sh): a 512 MiB write in front of a kernel, so that the kernel finds neither
 // its producer's output nor its weights in L2 / the 256 MB Infinity Cache.  Comparing a kernel's duration with and without it says
@@ -578,8 +595,7 @@ static int forward_chunk(grl_net *net, const uint8_t *lb, const uint8_t *ab, con
         GatherConv2 g{net->a1, n * 81};
         EpiBiasAct e{net->a2, 64, P + ConvOffsets::c2b, ACT_RELU};
         GemmTimer t(net, 2.0 * n * 81 * 512 * 64);
-        hipLaunchKernelGGL((gemm_rowk<256, 64, kW256M, kW256N, GatherConv2, EpiBiasAct>), dim3(1, (n * 81 + 255) / 256), dim3(64 * kW256M * kW256N), 0, st,
-                           g, PT + ConvOffsets::c2w, 512, 64, e);
+        launch_rowk<256, 64, kW256M, kW256N, GatherConv2, EpiBiasAct>(net, dim3(1, (n * 81 + 255) / 256), st, g, PT + ConvOffsets::c2w, 512, 64, e);
     }
     }
     if (!reuse_tail) {
@@ -589,16 +605,14 @@ static int forward_chunk(grl_net *net, const uint8_t *lb, const uint8_t *ab, con
         GatherConv3 g{net->a2, n * 49};
         EpiBiasAct e{net->a3, 64, P + ConvOffsets::c3b, ACT_RELU};
         GemmTimer t(net, 2.0 * n * 49 * 576 * 64);
-        hipLaunchKernelGGL((gemm_rowk<256, 64, kW256M, kW256N, GatherConv3, EpiBiasAct>), dim3(1, (n * 49 + 255) / 256), dim3(64 * kW256M * kW256N), 0, st,
-                           g, PT + ConvOffsets::c3w, 576, 64, e);
+        launch_rowk<256, 64, kW256M, kW256N, GatherConv3, EpiBiasAct>(net, dim3(1, (n * 49 + 255) / 256), st, g, PT + ConvOffsets::c3w, 576, 64, e);
     }
     net->prof_tag_cur = net->shared_trunk ? PT_DENSE_FWD : PT_PER_AGENT;
     auto dense = [&](const float *in, int K, const float *w, const float *b, int N, float *out) {
         DenseRows g{in, n, K, K};
         EpiBiasAct e{out, N, b, ACT_RELU};
         GemmTimer t(net, 2.0 * n * K * N);
-        hipLaunchKernelGGL((gemm_rowk<128, 128, kW128M, kW128N, DenseRows, EpiBiasAct>), dim3(N / 128, (n + 127) / 128), dim3(64 * kW128M * kW128N), 0, st, g,
-                           w, K, N, e);
+        launch_rowk<128, 128, kW128M, kW128N, DenseRows, EpiBiasAct>(net, dim3(N / 128, (n + 127) / 128), st, g, w, K, N, e);
     };
     if (!net->shared_trunk) dense(net->a3, 3136, PT + ConvOffsets::d1w, P + ConvOffsets::d1b, 512, net->d1);
     dense(net->d1, 512, PT + ConvOffsets::d2w, P + ConvOffsets::d2b, 256, net->d2);
@@ -737,6 +751,10 @@ int grl_net_create(grl_handle *h, const grl_net_config *cfg, grl_net **out) {
     {   // A/B switch of the conv2 corrections (default: GEMM)
         const char *lsk = getenv("GRL_NET_LOSS_SCALE");      // "off": S = 1, to show what the scale is for (tests)
         n->loss_scale_on = (lsk && strcmp(lsk, "off") == 0) ? 0 : 1;
+        const char *gm = getenv("GRL_NET_GEMM"), *rf = getenv("GRL_NET_RANGE_FALLBACK");
+        n->gemm_f32 = (gm && strcmp(gm, "f32") == 0) ? 1 : 0;                    // force the fp32-MFMA form from the start (tests, A/B)
+        n->range_fallback_on = (rf && strcmp(rf, "off") == 0) ? 0 : 1;            // off: a range violation fails the call (GRL_E_RANGE) and nothing else
+        n->range_fallbacks = 0; n->range_bits_last = 0; n->update_skipped_last = 0;
         const char *e2 = getenv("GRL_NET_EXPAND2");
         n->expand2_gemm = (e2 && strcmp(e2, "lds") == 0) ? 0 : 1;
     }
@@ -872,14 +890,26 @@ static int range_flag_init(grl_net *n) {
     return GRL_OK;
 }
 static int *range_flag_ptr(grl_net *n) { return g_range_flag_dev[n->h->cfg.device_id]; }
+// flag bits: 1 = some GEMM output of the work since the last check left the fp16 range; 2 = that was already so when the last
+// rollout ended (rollout_range_mark_kernel), i.e. the rollout's own actions / values come from invalid operands
 static int range_check(grl_net *n, const char *where) {
     int flag = 0;
     NET_HIP(n, hipMemcpy(&flag, range_flag_ptr(n), sizeof(int), hipMemcpyDeviceToHost));
+    n->range_bits_last = flag;
     if (!flag) return GRL_OK;
     NET_HIP(n, hipMemset(range_flag_ptr(n), 0, sizeof(int)));
     NET_HIP(n, hipDeviceSynchronize());
     return nfail(n, GRL_E_RANGE, std::string(where) + ": an activation or gradient exceeded 65504, the range of the fp16 matrix-pipe GEMMs "
                                                       "(include/goldsrl_net.h, Arithmetic); the results of this call are not valid");
+}
+
+// A pass that left the fp16 range: switch the net to the fp32-MFMA GEMMs (it stays there: grl_net_set_gemm_f32 switches back) and
+// tell the caller to run the work again.  Returns false when the fallback is off or the net already computes in fp32.
+static bool range_fall_back(grl_net *n) {
+    if (!n->range_fallback_on || n->gemm_f32) return false;
+    n->gemm_f32 = 1;
+    n->range_fallbacks += 1;
+    return true;
 }
 
 static int download_heads(grl_net *n, int B, float *mu_host, float *sigma_host, float *vs_host) {
@@ -897,7 +927,12 @@ int grl_net_predict(grl_net *n, float *mu_host, float *sigma_host, float *vs_hos
     grl_handle *h = n->h;
     int rc = forward_all(n, h->sw.lbins, h->sw.abins, h->sw.pos, h->E, n->mu, n->sigma, n->vs);
     if (rc) return rc;
-    return download_heads(n, h->E * 10, mu_host, sigma_host, vs_host);
+    rc = download_heads(n, h->E * 10, mu_host, sigma_host, vs_host);
+    if (rc == GRL_E_RANGE && range_fall_back(n)) {      // once more on the fp32 form
+        if ((rc = forward_all(n, h->sw.lbins, h->sw.abins, h->sw.pos, h->E, n->mu, n->sigma, n->vs))) return rc;
+        rc = download_heads(n, h->E * 10, mu_host, sigma_host, vs_host);
+    }
+    return rc;
 }
 
 int grl_net_predict_obs(grl_net *n, int32_t n_envs, const uint8_t *lb, const uint8_t *ab, const uint8_t *pos, float *mu_host,
@@ -911,7 +946,28 @@ int grl_net_predict_obs(grl_net *n, int32_t n_envs, const uint8_t *lb, const uin
     NET_HIP(n, hipMemcpyAsync(n->tmp_pos, pos, (size_t)n_envs * 20, hipMemcpyHostToDevice, n->h->stream));
     rc = forward_all(n, n->tmp_lb, n->tmp_ab, n->tmp_pos, n_envs, n->mu, n->sigma, n->vs);
     if (rc) return rc;
-    return download_heads(n, n_envs * 10, mu_host, sigma_host, vs_host);
+    rc = download_heads(n, n_envs * 10, mu_host, sigma_host, vs_host);
+    if (rc == GRL_E_RANGE && range_fall_back(n)) {
+        if ((rc = forward_all(n, n->tmp_lb, n->tmp_ab, n->tmp_pos, n_envs, n->mu, n->sigma, n->vs))) return rc;
+        rc = download_heads(n, n_envs * 10, mu_host, sigma_host, vs_host);
+    }
+    return rc;
+}
+
+int grl_net_range_info(grl_net *n, int32_t *gemm_f32, int32_t *fallbacks, int32_t *update_skipped) {
+    if (!n) return GRL_E_INVALID;
+    if (gemm_f32) *gemm_f32 = n->gemm_f32;
+    if (fallbacks) *fallbacks = n->range_fallbacks;
+    if (update_skipped) *update_skipped = n->update_skipped_last;
+    return GRL_OK;
+}
+
+int grl_net_set_gemm_f32(grl_net *n, int32_t on) {
+    if (!n) return GRL_E_INVALID;
+    hipSetDevice(n->h->cfg.device_id);
+    NET_HIP(n, hipStreamSynchronize(n->h->stream));
+    n->gemm_f32 = on ? 1 : 0;
+    return GRL_OK;
 }
 
 static int read_activation_impl(grl_net *n, const char *which, float *host, size_t bytes);

@@ -598,13 +598,36 @@ constexpr float kF16Max = 65504.f;
 constexpr int kW128M = 4, kW128N = 2, kW256M = 8, kW256N = 1;
 __device__ __forceinline__ int swz(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }
 
+// ---- the fp32 form (template flag F32 of gemm_rowk / gemm_tn; net_conv.hip switches a net to it after a GRL_E_RANGE pass).
+// The SAME LDS bytes hold the raw fp32 tile instead of the two fp16 planes: [row][32 floats], the eight 16-byte chunks of a row
+// XOR-swizzled by row & 7 (staging stores cover whole rows; a fragment read -- lane l: row l & 15, k = 4 j + (l >> 4) -- puts the
+// 64 lanes on 32 banks twice, the minimum for a 4-byte read).  One K = 32 step is eight v_mfma_f32_16x16x4_f32 per 16 x 16 tile
+// into ONE accumulator set: no operand range beyond fp32's, ~5x the matrix-pipe time of the three-product form.
+__device__ __forceinline__ int f32_off(int row, int k) { return row * 32 + ((((k >> 2) ^ (row & 7)) << 2) | (k & 3)); }
+template <int TM, int TN>
+__device__ __forceinline__ void mfma_f32_step(const float *__restrict__ Af, const float *__restrict__ Bf, int arow, int brow, int kg,
+                                              f32x4 (&acc)[TM][TN]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float av[TM], bv[TN];
+#pragma unroll
+        for (int a = 0; a < TM; ++a) av[a] = Af[f32_off(arow + a * 16, 4 * j + kg)];
+#pragma unroll
+        for (int b = 0; b < TN; ++b) bv[b] = Bf[f32_off(brow + b * 16, 4 * j + kg)];
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+    }
+}
+
 // ---------------------------------------------------------------------------- C = A(rowk) * Bt^T
 // Four or eight waves per workgroup (WGM x WGN).  The eight-wave forms keep a tile's bytes per FLOP and halve the wave tile
 // (32 x 64: 64 accumulator registers instead of 128), so four waves fit a SIMD instead of two: with three MFMAs per product the
 // loop waits on its loads and barriers more than on the matrix pipe, and more resident waves cover those waits (+4-18 % on the
 // dense1 shapes, most on short K: tools/ubench/gemm_f16x3.hip).  The second launch bound is waves per SIMD (HIP-Clang): two
 // workgroups per CU either way, i.e. a 256- or 128-register budget.
-template <int BM, int BN, int WGM, int WGN, class AG, class Epi, bool XCD_ORDER = true, bool FENCE = true>
+template <int BM, int BN, int WGM, int WGN, class AG, class Epi, bool XCD_ORDER = true, bool FENCE = true, bool F32 = false>
 __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void gemm_rowk(AG ag, const float *__restrict__ Bt, int ldb, int N, Epi epi) {
     constexpr int BK = 32, LDH = kLdh, NT = 64 * WGM * WGN, RPP = NT / 8;          // RPP: tile rows staged per pass (8 threads per row)
     constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 16, TN = WN / 16;       // 16x16 MFMA tiles per wave
@@ -674,12 +697,16 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void gemm_rowk(AG ag
         if (NB > 2) rb2 = *reinterpret_cast<const float4 *>(brow0 + (long)2 * RPP * ldb + bko);            \
         if (NB > 2) rb3 = *reinterpret_cast<const float4 *>(brow0 + (long)3 * RPP * ldb + bko);            \
     }
-#define GRL_STORE_PLANES(S_, o_, v4_)                                                                      \
+#define GRL_STORE_PLANES(S_, row_, v4_)                                                                    \
     {                                                                                                      \
-        uint2 h_, l_;                                                                                      \
-        split4((v4_).x, (v4_).y, (v4_).z, (v4_).w, h_, l_);                                                \
-        *reinterpret_cast<uint2 *>(&S_[0][o_]) = h_;                                                       \
-        *reinterpret_cast<uint2 *>(&S_[1][o_]) = l_;                                                       \
+        if constexpr (F32) {                                                                               \
+            *reinterpret_cast<float4 *>(reinterpret_cast<float *>(&S_[0][0]) + f32_off(row_, tk4)) = (v4_); \
+        } else {                                                                                           \
+            uint2 h_, l_;                                                                                  \
+            split4((v4_).x, (v4_).y, (v4_).z, (v4_).w, h_, l_);                                            \
+            *reinterpret_cast<uint2 *>(&S_[0][(row_) * LDH + wo]) = h_;                                    \
+            *reinterpret_cast<uint2 *>(&S_[1][(row_) * LDH + wo]) = l_;                                    \
+        }                                                                                                  \
     }
 #define GRL_STORE_TILE()                                                                                   \
     {                                                                                                      \
@@ -688,12 +715,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void gemm_rowk(AG ag
             float4 t4 = ra[i];                                                                             \
             t4.x = v ? t4.x : 0.f; t4.y = v ? t4.y : 0.f; t4.z = v ? t4.z : 0.f; t4.w = v ? t4.w : 0.f;    \
             if (AG::kRelu) { t4.x = fmaxf(t4.x, 0.f); t4.y = fmaxf(t4.y, 0.f); t4.z = fmaxf(t4.z, 0.f); t4.w = fmaxf(t4.w, 0.f); } \
-            GRL_STORE_PLANES(As, (trow + RPP * i) * LDH + wo, t4)                                          \
+            GRL_STORE_PLANES(As, trow + RPP * i, t4)                                                       \
         }                                                                                                  \
-        GRL_STORE_PLANES(Bs, trow * LDH + wo, rb0)                                                         \
-        if (NB > 1) GRL_STORE_PLANES(Bs, (trow + RPP) * LDH + wo, rb1)                                     \
-        if (NB > 2) GRL_STORE_PLANES(Bs, (trow + 2 * RPP) * LDH + wo, rb2)                                 \
-        if (NB > 2) GRL_STORE_PLANES(Bs, (trow + 3 * RPP) * LDH + wo, rb3)                                 \
+        GRL_STORE_PLANES(Bs, trow, rb0)                                                                    \
+        if (NB > 1) GRL_STORE_PLANES(Bs, trow + RPP, rb1)                                                  \
+        if (NB > 2) GRL_STORE_PLANES(Bs, trow + 2 * RPP, rb2)                                              \
+        if (NB > 2) GRL_STORE_PLANES(Bs, trow + 3 * RPP, rb3)                                              \
     }
 
     f32x4 acc[TM][TN], acl[TM][TN];
@@ -725,7 +752,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void gemm_rowk(AG ag
         }
         if constexpr (FENCE) { GRL_SCHED_FENCE }
         {   // one K = 32 step per tile
-            if constexpr (TM < TN) {      // keep the smaller operand's fragments live, stream the other one (fewer registers)
+            if constexpr (F32) {
+                mfma_f32_step<TM, TN>(reinterpret_cast<const float *>(&As[0][0]), reinterpret_cast<const float *>(&Bs[0][0]), wm * WM + l16,
+                                      wn * WN + l16, kg, acc);
+            } else if constexpr (TM < TN) {      // keep the smaller operand's fragments live, stream the other one (fewer registers)
                 f16x8 af[TM][2];
 #pragma unroll
                 for (int a = 0; a < TM; ++a)
@@ -760,12 +790,14 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void gemm_rowk(AG ag
         kt = ktn;
     }
     // the cross terms carry 2^11
+    if constexpr (!F32) {
 #pragma unroll
-    for (int a = 0; a < TM; ++a)
+        for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int b = 0; b < TN; ++b)
+            for (int b = 0; b < TN; ++b)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[a][b][r] = __builtin_fmaf(acl[a][b][r], 1.0f / kLowScale, acc[a][b][r]);
+                for (int r = 0; r < 4; ++r) acc[a][b][r] = __builtin_fmaf(acl[a][b][r], 1.0f / kLowScale, acc[a][b][r]);
+    }
     // C/D map of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + reg.  Two passes: all of the epilogue's loads, then
     // the stores (see the epilogue structs).
     const int erow = m0 + wm * WM + 4 * kg, ecol = n0 + wn * WN + l16;
@@ -800,7 +832,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void gemm_rowk(AG ag
                 const float gv = epi_add_aux<Epi>::value ? acc[a][b][r] + eax[a][b][r] : acc[a][b][r];
                 out_of_range |= !(fabsf(gv) <= kF16Max);
             }
-    if (out_of_range) atomicOr(g_gemm_range_flag, 1);
+    if (!F32 && out_of_range) atomicOr(g_gemm_range_flag, 1);      // the fp32 form has no operand range to guard
     if constexpr (Epi::kColSum) {      // column sums of the stored values over this wave's rows, in a fixed order
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
@@ -847,7 +879,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void gemm_rowk(AG ag
 // NA consecutive rows of the same four columns and writes each column's NA values (packed bf16) to the transposed LDS
 // tile [column][m].  Column 4*c4 + j sits in LDS row j*(BM/4) + c4, which spreads a store's lanes over the banks; the
 // epilogue undoes the permutation.
-template <int BM, int BN, int WGM, int WGN, class AG, int XCD_ORDER = 1>
+template <int BM, int BN, int WGM, int WGN, class AG, int XCD_ORDER = 1, bool F32 = false>
 __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void gemm_tn(AG ag, const float *__restrict__ dY, int J, int mc, float *__restrict__ slab) {
     constexpr int BK = 32, LDH = kLdh, NT = 64 * WGM * WGN;
     constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 16, TN = WN / 16;
@@ -944,9 +976,16 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void gemm_tn(AG ag, 
     }
     // tile row rho, reduction position m (0..31) -> swizzled LDS offset
 #define GRL_TN_OFF(rho_, m_) ((rho_) * LDH + ((((m_) >> 3) ^ swz(rho_)) << 3) + ((m_) & 7))
-    // one column's NV consecutive-m values -> NV packed fp16 per plane at S[p][o_]
-#define GRL_STORE_RUN(S_, NV_, o_, r_, comp_)                                                                      \
+    // one column's NV consecutive-m values -> NV packed fp16 per plane at S[p][GRL_TN_OFF(rho_, m_)] (F32: NV floats of the fp32 tile)
+#define GRL_STORE_RUN(S_, NV_, rho_, m_, r_, comp_)                                                                \
     {                                                                                                              \
+        if constexpr (F32) {                                                                                       \
+            float *f_ = reinterpret_cast<float *>(&S_[0][0]) + f32_off(rho_, m_);                                  \
+            if (NV_ == 4) *reinterpret_cast<float4 *>(f_) = make_float4(r_[0].comp_, r_[1 % NV_].comp_, r_[2 % NV_].comp_, r_[3 % NV_].comp_); \
+            else if (NV_ == 2) *reinterpret_cast<float2 *>(f_) = make_float2(r_[0].comp_, r_[1 % NV_].comp_);      \
+            else *f_ = r_[0].comp_;                                                                                \
+        } else {                                                                                                   \
+        const int o_ = GRL_TN_OFF(rho_, m_);                                                                       \
         if (NV_ == 4) {                                                                                            \
             uint2 h_, l_;                                                                                          \
             split4(r_[0].comp_, r_[1 % NV_].comp_, r_[2 % NV_].comp_, r_[3 % NV_].comp_, h_, l_);                  \
@@ -963,6 +1002,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void gemm_tn(AG ag, 
                 S_[1][o_] = (unsigned short)(l_ & 0xFFFFu);                                                        \
             }                                                                                                      \
         }                                                                                                          \
+        }                                                                                                          \
     }
 #define GRL_STORE_TILE()                                                                                           \
     {                                                                                                              \
@@ -973,17 +1013,17 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void gemm_tn(AG ag, 
             if (AG::kRelu) { t4.x = fmaxf(t4.x, 0.f); t4.y = fmaxf(t4.y, 0.f); t4.z = fmaxf(t4.z, 0.f); t4.w = fmaxf(t4.w, 0.f); } \
             ra[i] = t4;                                                                                            \
         }                                                                                                          \
-        GRL_STORE_RUN(As, NA, GRL_TN_OFF(0 * A4 + ca, ma), ra, x)                                                  \
-        GRL_STORE_RUN(As, NA, GRL_TN_OFF(1 * A4 + ca, ma), ra, y)                                                  \
-        GRL_STORE_RUN(As, NA, GRL_TN_OFF(2 * A4 + ca, ma), ra, z)                                                  \
-        GRL_STORE_RUN(As, NA, GRL_TN_OFF(3 * A4 + ca, ma), ra, w)                                                  \
+        GRL_STORE_RUN(As, NA, 0 * A4 + ca, ma, ra, x)                                                  \
+        GRL_STORE_RUN(As, NA, 1 * A4 + ca, ma, ra, y)                                                  \
+        GRL_STORE_RUN(As, NA, 2 * A4 + ca, ma, ra, z)                                                  \
+        GRL_STORE_RUN(As, NA, 3 * A4 + ca, ma, ra, w)                                                  \
         _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                           \
             const bool v = (vmb >> i) & 1u;                                                                        \
             float4 t4 = rb[i];                                                                                     \
             t4.x = v ? t4.x : 0.f; t4.y = v ? t4.y : 0.f; t4.z = v ? t4.z : 0.f; t4.w = v ? t4.w : 0.f;            \
             rb[i] = t4;                                                                                            \
         }                                                                                                          \
-        if (NB == 1) {      /* one row per thread: trade two columns with the thread holding the neighbouring row (same columns) */ \
+        if (NB == 1 && !F32) {      /* one row per thread: trade two columns with the thread holding the neighbouring row (same columns) */ \
             const bool odd = gb & 1;                                                                               \
             const float4 t4 = rb[0];                                                                               \
             const float o0 = __shfl_xor(odd ? t4.x : t4.z, B4), o1 = __shfl_xor(odd ? t4.y : t4.w, B4);            \
@@ -996,10 +1036,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void gemm_tn(AG ag, 
             *reinterpret_cast<unsigned *>(&Bs[0][q1]) = h1;                                                        \
             *reinterpret_cast<unsigned *>(&Bs[1][q1]) = l1;                                                        \
         } else {                                                                                                   \
-        GRL_STORE_RUN(Bs, NB, GRL_TN_OFF(0 * B4 + cb, mb), rb, x)                                                  \
-        GRL_STORE_RUN(Bs, NB, GRL_TN_OFF(1 * B4 + cb, mb), rb, y)                                                  \
-        GRL_STORE_RUN(Bs, NB, GRL_TN_OFF(2 * B4 + cb, mb), rb, z)                                                  \
-        GRL_STORE_RUN(Bs, NB, GRL_TN_OFF(3 * B4 + cb, mb), rb, w)                                                  \
+        GRL_STORE_RUN(Bs, NB, 0 * B4 + cb, mb, rb, x)                                                  \
+        GRL_STORE_RUN(Bs, NB, 1 * B4 + cb, mb, rb, y)                                                  \
+        GRL_STORE_RUN(Bs, NB, 2 * B4 + cb, mb, rb, z)                                                  \
+        GRL_STORE_RUN(Bs, NB, 3 * B4 + cb, mb, rb, w)                                                  \
         }                                                                                                          \
     }
     f32x4 acc[TM][TN], acl[TM][TN];
@@ -1023,7 +1063,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void gemm_tn(AG ag, 
             GRL_LOAD_TILE()                  // rows mt + BK .. (row 0, masked, past the end of the range)
             GRL_LOAD_IDX(mt + 2 * BK)
             {
-                if constexpr (TM < TN) {      // keep the smaller operand's fragments live, stream the other one (fewer registers)
+                if constexpr (F32) {
+                    mfma_f32_step<TM, TN>(reinterpret_cast<const float *>(&As[0][0]), reinterpret_cast<const float *>(&Bs[0][0]),
+                                          wm * WM + l16, wn * WN + l16, kg, acc);
+                } else if constexpr (TM < TN) {      // keep the smaller operand's fragments live, stream the other one (fewer registers)
                     f16x8 af[TM][2];
 #pragma unroll
                     for (int a = 0; a < TM; ++a)
@@ -1057,12 +1100,14 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void gemm_tn(AG ag, 
         }
     }
     // the cross terms carry 2^11
+    if constexpr (!F32) {
 #pragma unroll
-    for (int a = 0; a < TM; ++a)
+        for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int b = 0; b < TN; ++b)
+            for (int b = 0; b < TN; ++b)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[a][b][r] = __builtin_fmaf(acl[a][b][r], 1.0f / kLowScale, acc[a][b][r]);
+                for (int r = 0; r < 4; ++r) acc[a][b][r] = __builtin_fmaf(acl[a][b][r], 1.0f / kLowScale, acc[a][b][r]);
+    }
     float *out = slab + (long)bz * I * J;
 #pragma unroll
     for (int a = 0; a < TM; ++a)

@@ -43,6 +43,8 @@ NET_SIGNATURES = {
     "grl_net_comm_broadcast_params": (C.c_int, [_P, _I]),
     "grl_net_comm_destroy": (C.c_int, [_P]),
     "grl_net_comm_info": (C.c_int, [_P, _P, _P, _P, _P, _P]),
+    "grl_net_range_info": (C.c_int, [_P, _P, _P, _P]),
+    "grl_net_set_gemm_f32": (C.c_int, [_P, C.c_int32]),
     "grl_net_profile_enable": (C.c_int, [_P, _I]),
     "grl_net_profile_read": (C.c_int, [_P, C.POINTER(_I), C.POINTER(C.c_float), C.POINTER(C.c_double)]),
     "grl_net_profile_read_tags": (C.c_int, [_P, _I, _P, _P, _P]),
@@ -255,6 +257,16 @@ class ConvNet(object):
 
     def comm_destroy(self):
         self._check(self.lib.grl_net_comm_destroy(self.n))
+
+    def range_info(self):
+        """Arithmetic form of the GEMMs: 'gemm_f32' once a range violation (or set_gemm_f32) moved the net to the fp32 form,
+        'fallbacks' = how often that happened, 'update_skipped' = the last train_rollout* call gave its update up."""
+        f32, fb, sk = C.c_int32(), C.c_int32(), C.c_int32()
+        self._check(self.lib.grl_net_range_info(self.n, C.byref(f32), C.byref(fb), C.byref(sk)))
+        return {"gemm_f32": bool(f32.value), "fallbacks": fb.value, "update_skipped": bool(sk.value)}
+
+    def set_gemm_f32(self, on=True):
+        self._check(self.lib.grl_net_set_gemm_f32(self.n, 1 if on else 0))
 
     def profile_enable(self, on=True):
         self._check(self.lib.grl_net_profile_enable(self.n, 1 if on else 0))

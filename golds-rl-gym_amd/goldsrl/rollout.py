@@ -23,6 +23,13 @@ class _GradientExchange(object):
             raise err if err else RuntimeError("the gradient pass failed on another rank; no replica was updated")
         if err:
             raise err
+        # a conv net whose ROLLOUT left the fp16 range gave this update up (goldsrl_net.h, Arithmetic): then no replica applies one
+        skipped = 1 if (hasattr(self.net, "range_info") and self.net.range_info()["update_skipped"]) else 0
+        if self.ranks is not None:
+            skipped = int(self.ranks.max(skipped))
+        if skipped:
+            nan = float("nan")
+            return {"loss": nan, "policy_loss": nan, "critic_loss_mean": nan, "global_norm": nan}
         summed, world = self.host_allreduce(self.net.get_grads())
         self.net.set_grads(summed)
         return self.net.apply_grads(self.lr, 1.0 / world)

@@ -14,7 +14,12 @@
  * on the fp16 matrix pipe with every fp32 operand split into two fp16 terms (22-23 significand bits; csrc/net_gemm.h), which
  * measures closer to a float64 evaluation than a plain float32 one.  Range contract of that form: activations and weights
  * below 65 504 in magnitude.  Nothing is clamped: every GEMM checks its output tile, and the first call that synchronises
- * after a violation (predict, train_*, apply_grads) returns GRL_E_RANGE instead of results computed from inf operands.
+ * after a violation (predict, train_*, apply_grads) does not return results computed from inf operands.  By default it switches the
+ * net to the fp32 form of the same GEMM kernels (v_mfma_f32_16x16x4_f32, no range beyond float32's, ~5x the matrix-pipe time; the net
+ * stays there until grl_net_set_gemm_f32(net, 0)) and runs the work again: predict and train_obs in full; a gradient step over a
+ * rollout runs again when only its backward pass overflowed, and is given up (GRL_OK, NaN statistics, update_skipped = 1 in
+ * grl_net_range_info; parameters and Adam moments untouched) when the rollout's own forward passes did -- the next rollout is valid.
+ * GRL_NET_RANGE_FALLBACK=off in the environment keeps the hard failure (GRL_E_RANGE); GRL_NET_GEMM=f32 starts on the fp32 form.
  * Gradient passes pick an exact power-of-two loss scale per call, so advantages / targets of any float32 magnitude are fine.  GRL_NET_LOSS_SCALE=off in the environment disables that scale (diagnostic only).
  */
 #ifndef GOLDSRL_NET_H
@@ -121,13 +126,21 @@ int grl_net_read_activation(grl_net *net, const char *which, float *host, size_t
  * rollout over xGMI (no counterpart in the reference, which is single-device: actor_learner.py:70-75).
  * Rank 0 calls grl_comm_unique_id and ships the bytes to the other ranks by any means (goldsrl/distributed.py uses its own
  * TCP store on MASTER_ADDR); every rank then calls grl_net_comm_init.  Afterwards grl_net_train_* all-reduces gradients before
- * clip+Adam, so parameters stay replicated; the GEMMs' range flag is max-reduced in the same group, so a GRL_E_RANGE pass
- * fails on EVERY rank and no replica is updated. */
+ * clip+Adam, so parameters stay replicated; the GEMMs' range flag is max-reduced in the same group, so a pass that left the fp16
+ * range is repeated on the fp32 form, given up, or (GRL_NET_RANGE_FALLBACK=off) failed on EVERY rank alike, and no replica is updated
+ * from it. */
 size_t grl_comm_unique_id_bytes(void);
 int grl_comm_unique_id(void *out, size_t bytes);
 int grl_net_comm_init(grl_net *net, const void *unique_id, size_t bytes, int32_t rank, int32_t world_size);
 int grl_net_comm_broadcast_params(grl_net *net, int32_t root);
 int grl_net_comm_destroy(grl_net *net);
+/* Arithmetic form of the GEMMs (see the header comment): *gemm_f32_out = 1 when the net computes on the fp32 form, *fallbacks_out = how
+ * often a range violation switched it there, *update_skipped_out = 1 when the LAST train_rollout* call gave its update up.  Any pointer
+ * may be NULL. */
+int grl_net_range_info(grl_net *net, int32_t *gemm_f32_out, int32_t *fallbacks_out, int32_t *update_skipped_out);
+/* 1: compute every GEMM on the fp32 form; 0: back to the three-product fp16 form. */
+int grl_net_set_gemm_f32(grl_net *net, int32_t on);
+
 /* What RCCL itself says about the attached communicator: ncclCommCount / ncclCommUserRank (0 / -1 without one), and the
  * gradient all-reduces so far: calls, summed and last duration in ms (HIP events around the collective on the handle's stream).
  * Any out pointer may be NULL. */

@@ -170,12 +170,14 @@ def test_without_the_loss_scale_small_head_gradients_are_lost(monkeypatch):
     assert out["on"] == 0.0 and out["off"] > 1e-3, out
 
 
-def test_operands_beyond_the_fp16_range_fail_the_call():
+def test_operands_beyond_the_fp16_range_fail_the_call(monkeypatch):
     """Range contract of the fp16 matrix-pipe GEMMs (include/goldsrl_net.h): an activation above 65 504 cannot be represented in the
     operand planes (it would become inf, and ReLU's max would turn the NaNs that follow into plausible zeros), so every GEMM checks
-    its output tile and the call that synchronises next fails with GRL_E_RANGE instead of returning such results."""
+    its output tile and -- with the fp32 fallback switched off -- the call that synchronises next fails with GRL_E_RANGE instead of
+    returning such results."""
     from goldsrl import _ffi
     E = 2
+    monkeypatch.setenv("GRL_NET_RANGE_FALLBACK", "off")      # read when the net is created: the hard failure, no switch to fp32 GEMMs
     eng, net, p, states, obs = _setup(E)
     flat = net.get_params().copy()
     q = NN.unflatten_params(flat.astype(np.float64))
@@ -201,6 +203,82 @@ def test_operands_beyond_the_fp16_range_fail_the_call():
     got = net.read_activation("d1", ref.shape).astype(np.float64)
     assert np.abs(ref).max() > 1e3 and np.abs(got - ref).max() / np.abs(ref).max() < 2e-5
     np.testing.assert_allclose(out["mu"], mu, atol=1e-4)
+
+
+def test_a_range_violation_moves_the_net_to_fp32_gemms_and_the_call_proceeds():
+    """The reference's fp32 graph has no operand range; by default this net does not either: a pass whose activations leave the
+    fp16 range is run again on the fp32 form of the same GEMM kernels (v_mfma_f32_16x16x4_f32) and the net stays there.  predict and
+    train_obs against the float64 oracle with relu(conv2) = 3e5, the counters of grl_net_range_info, and the way back."""
+    E = 2
+    eng, net, p, states, obs = _setup(E)
+    assert net.range_info() == {"gemm_f32": False, "fallbacks": 0, "update_skipped": False}
+    flat = net.get_params().copy()
+    q = NN.unflatten_params(flat.astype(np.float64))
+    q["conv2_b"] = q["conv2_b"] + 3.0e5
+    q["conv3_w"] = q["conv3_w"] * 1e-5          # keeps the heads out of saturation, so that they can be compared
+    net.set_params(NN.flatten_params(q).astype(np.float32))
+    q = NN.unflatten_params(net.get_params().astype(np.float64))
+    out = net.predict()
+    assert net.range_info() == {"gemm_f32": True, "fallbacks": 1, "update_skipped": False}
+    mu, sigma, vs, c = NN.conv_forward(q, states, 1000.0, keep=True)
+    assert np.abs(c["a2"]).max() > 65504
+    got = net.read_activation("d1", c["d1"].shape).astype(np.float64)
+    assert np.abs(got - c["d1"]).max() / np.abs(c["d1"]).max() < 2e-5
+    np.testing.assert_allclose(out["mu"], mu, atol=2e-4)
+    np.testing.assert_allclose(out["sigma"], sigma, atol=2e-4)
+    np.testing.assert_allclose(out["vs"], vs, rtol=2e-4, atol=1e-3)
+    # the gradient step on the fp32 form, against the oracle's gradient of the same loss
+    act, adv, y = _train_inputs(E)
+    stats = net.train_obs(*obs, act, adv, y, lr=0.0, apply_update=False)
+    assert np.isfinite(stats["global_norm"]) and net.range_info()["fallbacks"] == 1
+    got = NN.unflatten_params(net.get_grads().astype(np.float64))
+    loss, pl, cl, gref, _ = NN.conv_loss_and_grads(q, states, act.astype(np.float64), adv.astype(np.float64), y.astype(np.float64), 0.02, 1000.0)
+    np.testing.assert_allclose(stats["loss"], loss, rtol=1e-4)
+    for name, _ in NN.CONV_PARAM_SHAPES:
+        assert np.abs(got[name] - gref[name]).max() <= 3e-4 * (np.abs(gref[name]).max() + 1e-12), name
+    # a second net that overflows inside train_obs first: the whole call is repeated on the fp32 form, same gradient
+    eng2, net2, _, _, obs2 = _setup(E)
+    net2.set_params(net.get_params())
+    net2.train_obs(*obs2, act, adv, y, lr=0.0, apply_update=False)
+    assert net2.range_info()["gemm_f32"] and net2.range_info()["fallbacks"] == 1
+    np.testing.assert_array_equal(net2.get_grads(), net.get_grads())
+    # back inside the range and back on the fast form: the results of a net that never left it
+    net.set_params(flat)
+    net.set_gemm_f32(False)
+    eng3, net3, _, _, _ = _setup(E)
+    a, b = net.predict(), net3.predict()
+    for k in a:
+        np.testing.assert_array_equal(a[k], b[k])
+    assert not net.range_info()["gemm_f32"]
+    for n_ in (net, net2, net3):
+        n_.close()
+
+
+def test_a_rollout_that_left_the_range_gives_its_update_up_and_the_next_one_is_valid():
+    """A rollout whose forward passes overflowed drew its actions from invalid heads: the gradient step over it is given up
+    (GRL_OK, parameters and Adam moments untouched, update_skipped in grl_net_range_info), the net moves to the fp32 form, and
+    the next rollout + gradient step work and change the parameters."""
+    from goldsrl import _ffi, _ffi_net
+    E, T = 64, 3
+    eng = _ffi.Engine(_ffi.ENV_SWARM, E, seed=5)
+    eng.reset()
+    net = _ffi_net.ConvNet(eng)
+    q = NN.unflatten_params(_ffi_net.glorot_uniform_flat(seed=4).astype(np.float64))
+    q["conv2_b"] = q["conv2_b"] + 3.0e5
+    q["conv3_w"] = q["conv3_w"] * 1e-5
+    net.set_params(NN.flatten_params(q).astype(np.float32))
+    before = net.get_params().copy()
+    net.rollout(T, 0)
+    stats = net.train_rollout(1e-3)
+    info = net.range_info()
+    assert info == {"gemm_f32": True, "fallbacks": 1, "update_skipped": True} and np.isnan(stats["loss"])
+    np.testing.assert_array_equal(net.get_params(), before)
+    net.rollout(T, 0)
+    stats = net.train_rollout(1e-3)
+    assert np.isfinite(stats["loss"]) and np.isfinite(stats["global_norm"]) and not net.range_info()["update_skipped"]
+    after = net.get_params()
+    assert np.isfinite(after).all() and (after != before).any()
+    net.close()
 
 
 @pytest.mark.parametrize("A", [1, 3, 4])
