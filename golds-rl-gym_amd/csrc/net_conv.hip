@@ -118,7 +118,7 @@ struct grl_net : NetLane {
     float *w3f;                // w3f[(tap,co)][ci] = W3[tap][ci][co] (slot product GEMM of conv3's forward)
     int shared_trunk;
     // GEMM arithmetic: 0 = three fp16 products (operands must stay inside the fp16 range), 1 = v_mfma_f32_16x16x4_f32 (no range
-    // limit, ~5x the matrix-pipe time).  A pass that raised the range flag switches the net to 1 (range_fallback below).
+    // limit, 103 instead of 200 TFLOP/s).  A pass that raised the range flag switches the net to 1 (range_fallback below).
     int gemm_f32, range_fallback_on, range_fallbacks, range_bits_last, update_skipped_last;
     int loss_scale_on;         // per-pass power-of-two scale of the head gradients (net_train.inc); GRL_NET_LOSS_SCALE=off disables it
     int expand2_gemm, ctiles;  // conv2's per-agent corrections as a class-sorted GEMM (default) or the LDS-resident kernel (GRL_NET_EXPAND2=lds)
