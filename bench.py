@@ -31,6 +31,11 @@ import time
 
 import numpy as np
 
+# The host driver of this pool supports dmabuf IPC only: without this RCCL's intra-node transport fails with
+# `hipIpcGetMemHandle: invalid argument`.  The GPU boxes export it already; a launcher that scrubs the environment must not lose it.
+# Set before anything loads the HIP runtime.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "golds-rl-gym_amd")):
     if p not in sys.path:

@@ -178,3 +178,49 @@ def test_exchange_setup_phases_keep_the_ranks_together(tmp_path):
         "r.close()\n" % (os.path.join(ROOT, "golds-rl-gym_amd"), os.path.join(ROOT, "tests"), str(tmp_path)))
     assert D.spawn_local_ranks([sys.executable, str(child)], 2) == 0
     assert sorted(p.name for p in tmp_path.iterdir() if p.name.startswith("ok")) == ["ok0", "ok1"]
+
+
+def test_host_exchange_update_is_taken_or_left_by_every_rank_together(tmp_path):
+    """goldsrl.rollout._GradientExchange._update on the host path, two ranks over the TCP store: a local gradient pass that raises
+    on ONE rank makes both raise before the exchange; a rank whose rollout left the fp16 range (update_skipped in range_info) makes
+    BOTH return NaN statistics without applying anything; otherwise both apply the mean of the ranks' gradients."""
+    from goldsrl import distributed as D
+    child = tmp_path / "child.py"
+    child.write_text(
+        "import math, os, sys\n"
+        "import numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from goldsrl import distributed as D\n"
+        "from goldsrl.rollout import _GradientExchange\n"
+        "r = D.Ranks().init(timeout_s=120)\n"
+        "class Net(object):\n"
+        "    def __init__(self, fail, skipped):\n"
+        "        self.fail, self.skipped, self.applied, self.g = fail, skipped, None, np.full(4, r.rank + 1.0, np.float32)\n"
+        "    def train_rollout_grads(self):\n"
+        "        if self.fail: raise RuntimeError('local pass failed (test)')\n"
+        "    def range_info(self):\n"
+        "        return {'gemm_f32': self.skipped, 'fallbacks': int(self.skipped), 'update_skipped': self.skipped}\n"
+        "    def get_grads(self): return self.g\n"
+        "    def set_grads(self, g): self.g = g\n"
+        "    def apply_grads(self, lr, scale):\n"
+        "        self.applied = self.g * scale\n"
+        "        return {'loss': 1.0}\n"
+        "def make(fail=False, skipped=False):\n"
+        "    x = _GradientExchange(); x.net = Net(fail, skipped); x.lr = 1e-3; x.ranks = r\n"
+        "    x.host_allreduce = lambda g: (r.allreduce_sum_f32(g), r.world)\n"
+        "    return x\n"
+        "x = make(fail=(r.rank == 1))\n"
+        "try:\n"
+        "    x._update(); raise SystemExit('no error on rank %%d' %% r.rank)\n"
+        "except RuntimeError as e:\n"
+        "    assert ('test' in str(e)) == (r.rank == 1) and x.net.applied is None\n"
+        "x = make(skipped=(r.rank == 0))\n"
+        "s = x._update()\n"
+        "assert math.isnan(s['loss']) and x.net.applied is None\n"
+        "x = make()\n"
+        "s = x._update()\n"
+        "assert s == {'loss': 1.0} and np.array_equal(x.net.applied, np.full(4, 1.5, np.float32))\n"
+        "open(os.path.join(%r, 'ok%%d' %% r.rank), 'w').write('ok')\n"
+        "r.close()\n" % (os.path.join(ROOT, "golds-rl-gym_amd"), str(tmp_path)))
+    assert D.spawn_local_ranks([sys.executable, str(child)], 2) == 0
+    assert sorted(p.name for p in tmp_path.iterdir() if p.name.startswith("ok")) == ["ok0", "ok1"]
