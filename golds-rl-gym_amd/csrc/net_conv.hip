@@ -82,7 +82,9 @@ struct NetLane {
     float *a3sh, *d3, *ysh;
     unsigned long long *m3;    // ReLU mask of the agent's 5x5 patch of a3: 25 words of 64 channel bits per sample
     float *gd1sh, *gsh3, *g3p, *dz3p;     // gradient side: per-env sum of gd1, its dense1 data gradient, per-agent patch gradients
-    int *perm, *goffp, *blkcnt, *blkoff, *sbeg, *send, *sgrp;
+    int *perm, *goffp, *blkcnt, *blkoff, *sbeg, *send, *sgrp, *binbase;
+    unsigned short *pkey, *prank;      // sort key of a sample (group, column span, row span) and its rank inside its workgroup (net_patch.inc)
+    unsigned *smask, *tmask, *zmask;   // 25-bit patch support per sample / union per 128 sorted rows / per weight-gradient slice
     int2 *rowdesc;                     // gather descriptors of the compact slot rows (slot_rowdesc_kernel)
     int *sbase, *rowagent, *sblk;      // compact slot rows (net_shared.inc): prefix of per-sample slot counts, row -> sample, scan scratch
     signed char *tilegroup, *org;
@@ -119,6 +121,8 @@ struct grl_net : NetLane {
     int shared_trunk;
     // GEMM arithmetic: 0 = three fp16 products (operands must stay inside the fp16 range), 1 = v_mfma_f32_16x16x4_f32 (no range
     // limit, 103 instead of 200 TFLOP/s).  A pass that raised the range flag switches the net to 1 (range_fallback below).
+    double pfrac[3];           // executed share of the dense1 patch GEMMs' FLOPs in the last sorted chunk (profiling pass only; else 1)
+    int patch_skip;            // 1: the dense1 patch GEMMs skip what the support masks say is zero (GRL_PATCH_SKIP=off: the plain 5x5 patch)
     int gemm_f32, range_fallback_on, range_fallbacks, range_bits_last, update_skipped_last;
     int loss_scale_on;         // per-pass power-of-two scale of the head gradients (net_train.inc); GRL_NET_LOSS_SCALE=off disables it
     int expand2_gemm, ctiles;  // conv2's per-agent corrections as a class-sorted GEMM (default) or the LDS-resident kernel (GRL_NET_EXPAND2=lds)
@@ -665,8 +669,14 @@ static int alloc_lane_forward(grl_net *n) {
     if (rc == GRL_OK) rc = nalloc(n, &n->sbeg, n->pslices);
     if (rc == GRL_OK) rc = nalloc(n, &n->send, n->pslices);
     if (rc == GRL_OK) rc = nalloc(n, &n->sgrp, n->pslices);
-    if (rc == GRL_OK) rc = nalloc(n, &n->blkcnt, ((c + 255) / 256) * 9);
-    if (rc == GRL_OK) rc = nalloc(n, &n->blkoff, ((c + 255) / 256) * 9);
+    if (rc == GRL_OK) rc = nalloc(n, &n->blkcnt, ((c + 255) / 256) * PATCH_KEYS);
+    if (rc == GRL_OK) rc = nalloc(n, &n->blkoff, ((c + 255) / 256) * PATCH_KEYS);
+    if (rc == GRL_OK) rc = nalloc(n, &n->binbase, PATCH_KEYS);
+    if (rc == GRL_OK) rc = nalloc(n, &n->pkey, c);
+    if (rc == GRL_OK) rc = nalloc(n, &n->prank, c);
+    if (rc == GRL_OK) rc = nalloc(n, &n->smask, c);
+    if (rc == GRL_OK) rc = nalloc(n, &n->tmask, (size_t)n->ptiles * 2 + 2);
+    if (rc == GRL_OK) rc = nalloc(n, &n->zmask, (size_t)n->pslices);
     if (rc == GRL_OK) rc = nalloc(n, &n->tilegroup, (size_t)n->ptiles);
     if (rc == GRL_OK) rc = nalloc(n, &n->org, c);
     if (rc == GRL_OK) rc = nalloc(n, &n->sbase, c + 1);
@@ -755,6 +765,9 @@ int grl_net_create(grl_handle *h, const grl_net_config *cfg, grl_net **out) {
         n->gemm_f32 = (gm && strcmp(gm, "f32") == 0) ? 1 : 0;                    // force the fp32-MFMA form from the start (tests, A/B)
         n->range_fallback_on = (rf && strcmp(rf, "off") == 0) ? 0 : 1;            // off: a range violation fails the call (GRL_E_RANGE) and nothing else
         n->range_fallbacks = 0; n->range_bits_last = 0; n->update_skipped_last = 0;
+        const char *psk = getenv("GRL_PATCH_SKIP");
+        n->patch_skip = (psk && strcmp(psk, "off") == 0) ? 0 : 1;
+        n->pfrac[0] = n->pfrac[1] = n->pfrac[2] = 1.0;
         const char *e2 = getenv("GRL_NET_EXPAND2");
         n->expand2_gemm = (e2 && strcmp(e2, "lds") == 0) ? 0 : 1;
     }
@@ -1029,6 +1042,8 @@ static int read_activation_impl(grl_net *n, const char *which, float *host, size
     else if (w == "p1") { src = n->p1; per = 512; }
     else if (w == "v1") { src = n->v1; per = 512; }
     else if (w == "v2") { src = n->v2; per = 256; }
+    else if (w == "d3") { src = n->d3; per = 1600; }                                                   // compact patch differences (net_patch.inc)
+    else if (w == "smask") { src = reinterpret_cast<const float *>(n->smask); per = 1; }          // 25-bit patch supports, raw words
     else if (w == "gp1") { src = n->gp1; per = 512; }
     else if (w == "gv2") { src = n->gv2; per = 256; }
     else if (w == "gd2") { src = n->gd2; per = 256; }

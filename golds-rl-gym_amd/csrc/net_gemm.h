@@ -37,6 +37,7 @@
 #include <stdint.h>
 
 #include <type_traits>
+#include <utility>
 
 namespace grl {
 
@@ -300,6 +301,18 @@ struct PatchRows {
     const signed char *tilegroup;
     int rows, ld, k, mode;
     const int *sbeg, *send;      // gemm_tn only: grid z = slice of <= 1024 sorted rows inside one group (empty: sbeg == send)
+    // Support masks (net_patch.inc, patch_masks_kernel): inside a group the samples are sorted by the shape of what conv3 can make
+    // non-zero in their patch, and tmask[t] says for the 128 sorted rows of tile t which of the 25 patch pixels ANY of them can have
+    // non-zero (bit py * 5 + px).  Everything outside is an exact zero of d3, so the work on it is skipped: K-tiles of the forward
+    // (tile_ok), pixel columns of the data gradient (n_ok), pixel rows of the weight gradient (i_ok).  nullptr: no skipping.
+    const unsigned *tmask;
+    const unsigned *zmask;      // the same union per weight-gradient slice (rows [sbeg[z], send[z]))
+    __device__ __forceinline__ bool n_ok(int m0, int n0) const {      // gemm_rowk, BM = 256, mode 1: column tile n0 = one patch pixel
+        return mode != 1 || !tmask || (((tmask[m0 >> 7] | tmask[(m0 >> 7) + 1]) >> (n0 >> 6)) & 1u);
+    }
+    __device__ __forceinline__ bool i_ok(int z, int i0) const {      // gemm_tn: slice z, I tile i0 = one patch pixel
+        return !zmask || ((zmask[z] >> (i0 >> 6)) & 1u);
+    }
     __device__ __forceinline__ int2 ahandle(int m) const { return make_int2(perm[m], 0); }      // gemm_tn: fetched one tile ahead
     __device__ __forceinline__ bool hvalid(int2 h) const { return h.x >= 0; }                     // padding rows of the sorted layout
     __device__ __forceinline__ int bhandle(int m) const { return perm[m]; }
@@ -324,7 +337,9 @@ struct PatchRows {
         ty = tx = 0;
     }
     __device__ __forceinline__ bool ok(int iy0, int, int, int) const { return iy0 >= 0; }
-    __device__ __forceinline__ bool tile_ok(int, int) const { return true; }
+    __device__ __forceinline__ bool tile_ok(int m0, int k0) const {      // gemm_rowk, BM = 128, mode 0: K-tile k0 lies in one patch pixel
+        return mode != 0 || !tmask || ((tmask[m0 >> 7] >> (k0 >> 6)) & 1u);
+    }
     __device__ __forceinline__ bool tile_active(int m0) const { return tilegroup[m0 >> 8] >= 0; }
     __device__ __forceinline__ int bk(int k0, int m0) const {
         if (mode != 0) return k0;
@@ -621,6 +636,12 @@ __device__ __forceinline__ void mfma_f32_step(const float *__restrict__ Af, cons
     }
 }
 
+// optional hooks of a gather descriptor: whole output column tiles (gemm_rowk) / output row tiles (gemm_tn) known to be zero
+template <class T, class = void> struct ag_has_n_ok : std::false_type {};
+template <class T> struct ag_has_n_ok<T, std::void_t<decltype(std::declval<const T &>().n_ok(0, 0))>> : std::true_type {};
+template <class T, class = void> struct ag_has_i_ok : std::false_type {};
+template <class T> struct ag_has_i_ok<T, std::void_t<decltype(std::declval<const T &>().i_ok(0, 0))>> : std::true_type {};
+
 // ---------------------------------------------------------------------------- C = A(rowk) * Bt^T
 // Four or eight waves per workgroup (WGM x WGN).  The eight-wave forms keep a tile's bytes per FLOP and halve the wave tile
 // (32 x 64: 64 accumulator registers instead of 128), so four waves fit a SIMD instead of two: with three MFMAs per product the
@@ -656,6 +677,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void gemm_rowk(AG ag
     }
     const int m0 = by * BM, n0 = bx * BN;
     if (!ag.tile_active(m0)) return;     // block-uniform (padding tiles of the group-sorted layouts)
+    if constexpr (ag_has_n_ok<AG>::value) {      // a column tile that is zero for every row of the tile is neither computed nor stored:
+        if (!ag.n_ok(m0, n0)) return;            // its consumer knows the same masks (agent_dz3_kernel)
+    }
     const int M = ag.rows, K = ag.K();
     const int trow = tid >> 3, tk4 = (tid & 7) * 4;
     const int wo = (((tk4 >> 3) ^ swz(trow)) << 3) + (tk4 & 4);      // swizzled k offset of this thread's stores (rows trow + RPP i: same swizzle)
@@ -919,6 +943,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void gemm_tn(AG ag, 
     const int I = ag.K();
     int mbeg, mend;
     ag.mrange(bz, mc, mbeg, mend);
+    if constexpr (ag_has_i_ok<AG>::value) {      // output rows that are zero for the whole row range: no slab tile; the reduction
+        if (!ag.i_ok(bz, i0)) return;            // that follows knows the same masks (patch_dw_reduce_kernel)
+    }
 
     int toff, ty, tx;
     ag.tap(i0, toff, ty, tx);   // the BM-wide column run lies inside one tap row (checked on the host)

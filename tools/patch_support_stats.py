@@ -1,0 +1,34 @@
+"""How much of an agent's 5x5 dense1 patch can be non-zero?  From the agents' positions on the 84x84 grid (the engine's `positions`)
+the conv1 -> conv2 -> conv3 footprints follow; prints the mean share of the 25 patch pixels inside the footprint."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "golds-rl-gym_amd"))
+from goldsrl import _ffi  # noqa: E402
+from goldsrl import rollout as R  # noqa: E402
+
+
+def rows(ph):
+    o1 = [o for o in range(20) if 4 * o <= ph <= 4 * o + 7]
+    o2 = sorted({o for a in o1 for o in range(9) if 2 * o <= a <= 2 * o + 3})
+    r = sorted({x for o in o2 for x in range(o - 2, o + 1) if 0 <= x <= 6})
+    oy = min(max(min(o2) - 2, 0), 2)
+    return len(o2), (r[0] - oy, r[-1] - oy + 1)
+
+
+tab = [rows(p) for p in range(84)]
+E = 4096
+eng = _ffi.Engine(_ffi.ENV_SWARM, E, seed=1692)
+eng.reset()
+roll = R.ConvPolicyRollout(eng, 20, train=False)
+for it in range(26):
+    roll.run(); eng.wait()
+    pos = eng.read("positions").reshape(-1, 2).astype(int)
+    nr = np.array([tab[p][0] for p in pos[:, 0]]); nc = np.array([tab[p][0] for p in pos[:, 1]])
+    sr = np.array([tab[p][1][1] - tab[p][1][0] for p in pos[:, 0]]); sc = np.array([tab[p][1][1] - tab[p][1][0] for p in pos[:, 1]])
+    if it % 5 == 0: print("after %d rollouts: slots/agent %.2f, support %.2f x %.2f pixels = %.1f %% of the 25; positions in the outer 8 pixels: %.1f %%"
+          % (it + 1, (nr * nc).mean(), sr.mean(), sc.mean(), 100 * (sr * sc).mean() / 25,
+             100 * ((pos < 8) | (pos > 75)).any(axis=1).mean()))
