@@ -84,7 +84,8 @@ struct NetLane {
     float *gd1sh, *gsh3, *g3p, *dz3p;     // gradient side: per-env sum of gd1, its dense1 data gradient, per-agent patch gradients
     int *perm, *goffp, *blkcnt, *blkoff, *sbeg, *send, *sgrp, *binbase;
     unsigned short *pkey, *prank;      // sort key of a sample (group, column span, row span) and its rank inside its workgroup (net_patch.inc)
-    unsigned *smask, *tmask, *zmask;   // 25-bit patch support per sample / union per 128 sorted rows / per weight-gradient slice
+    unsigned *smask, *tmask, *zmask, *wmask;   // 25-bit patch support per sample / union per 128 sorted rows / per weight-gradient slice / slice union per sample
+    int *slot_of;                      // sorted slot of a sample (inverse of perm)
     int2 *rowdesc;                     // gather descriptors of the compact slot rows (slot_rowdesc_kernel)
     int *sbase, *rowagent, *sblk;      // compact slot rows (net_shared.inc): prefix of per-sample slot counts, row -> sample, scan scratch
     signed char *tilegroup, *org;
@@ -665,7 +666,7 @@ static int alloc_lane_forward(grl_net *n) {
     n->ws_a3sh = n->a3sh; n->ws_d3 = n->d3; n->ws_m3 = n->m3;
     n->ws_sraw = n->sraw; n->ws_a2sh = n->a2sh; n->ws_d2s = n->d2s; n->ws_m2s = n->m2s; n->ws_ulist = n->ulist;
     if (rc == GRL_OK) rc = nalloc(n, &n->perm, (size_t)n->ptiles * 256);
-    if (rc == GRL_OK) rc = nalloc(n, &n->goffp, 16);
+    if (rc == GRL_OK) rc = nalloc(n, &n->goffp, 32);
     if (rc == GRL_OK) rc = nalloc(n, &n->sbeg, n->pslices);
     if (rc == GRL_OK) rc = nalloc(n, &n->send, n->pslices);
     if (rc == GRL_OK) rc = nalloc(n, &n->sgrp, n->pslices);
@@ -677,6 +678,8 @@ static int alloc_lane_forward(grl_net *n) {
     if (rc == GRL_OK) rc = nalloc(n, &n->smask, c);
     if (rc == GRL_OK) rc = nalloc(n, &n->tmask, (size_t)n->ptiles * 2 + 2);
     if (rc == GRL_OK) rc = nalloc(n, &n->zmask, (size_t)n->pslices);
+    if (rc == GRL_OK) rc = nalloc(n, &n->wmask, c);
+    if (rc == GRL_OK) rc = nalloc(n, &n->slot_of, c);
     if (rc == GRL_OK) rc = nalloc(n, &n->tilegroup, (size_t)n->ptiles);
     if (rc == GRL_OK) rc = nalloc(n, &n->org, c);
     if (rc == GRL_OK) rc = nalloc(n, &n->sbase, c + 1);
@@ -1030,7 +1033,7 @@ static int read_activation_impl(grl_net *n, const char *which, float *host, size
         if (n->last_n <= 0) return nfail(n, GRL_E_STATE, "grl_net_read_activation: no forward pass yet");
         float *tmp = nullptr;
         NET_HIP(n, hipMalloc((void **)&tmp, need_a));
-        hipLaunchKernelGGL(materialize_a3_kernel, dim3(n->last_n), dim3(256), 0, n->h->stream, n->a3sh, n->d3, n->m3, n->org, tmp);
+        hipLaunchKernelGGL(materialize_a3_kernel, dim3(n->last_n), dim3(256), 0, n->h->stream, n->a3sh, n->d3, n->m3, n->org, n->patch_skip ? n->smask : nullptr, tmp);
         hipError_t e1 = hipStreamSynchronize(n->h->stream), e2 = hipMemcpy(host, tmp, bytes, hipMemcpyDeviceToHost);
         (void)hipFree(tmp);
         if (e1 != hipSuccess || e2 != hipSuccess) return nfail(n, GRL_E_HIP, "grl_net_read_activation: expanding a3 failed");
