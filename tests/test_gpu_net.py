@@ -548,6 +548,44 @@ def test_full_size_gradient_resident_equals_recomputed_and_is_reproducible():
     net.close()
 
 
+def test_patch_support_masks_change_nothing_but_the_work(monkeypatch):
+    """dense1's per-agent part multiplies a 5x5 patch of conv3 outputs of which only the rectangle the agent's touched conv2 pixels
+    reach can be non-zero; the GEMMs, the expansion and agent_dz3 skip the rest (net_patch.inc).  The skipped operands are exact
+    zeros, so heads, loss terms and the whole gradient must EQUAL those of the plain 5x5 evaluation (GRL_PATCH_SKIP=off) -- agents
+    on borders and corners (supports of 1x1 .. 5x5), a chunk size that leaves ragged tiles, 1 200 samples so that several
+    128-row tiles and shapes meet inside a group."""
+    from goldsrl import _ffi, _ffi_net
+    E = 120
+    eng = _ffi.Engine(_ffi.ENV_SWARM, E, seed=3)
+    eng.reset()
+    rng = np.random.RandomState(5)
+    edge = [0, 1, 2, 3, 5, 8, 75, 79, 80, 82, 83]
+    lb = rng.randint(0, 84, size=(E, 80, 2)).astype(np.uint8)
+    pos = np.zeros((E, 10, 2), np.uint8)
+    for e in range(E):
+        for a in range(10):
+            kind = (a + e) % 4
+            pos[e, a] = ((rng.choice(edge), rng.choice(edge)) if kind == 0 else (rng.randint(0, 84), rng.choice(edge)) if kind == 1
+                         else (rng.choice(edge), rng.randint(0, 84)) if kind == 2 else (rng.randint(0, 84), rng.randint(0, 84)))
+    ab = pos.copy()
+    act, adv, y = _train_inputs(E, seed=6)
+    flat = _ffi_net.glorot_uniform_flat(seed=7)
+    res = {}
+    for mode in ("on", "off"):
+        monkeypatch.setenv("GRL_PATCH_SKIP", mode)      # read when the net is created
+        net = _ffi_net.ConvNet(eng, max_chunk_samples=500)
+        net.set_params(flat)
+        out = net.predict_obs(lb, ab, pos)
+        stats = net.train_obs(lb, ab, pos, act, adv, y, lr=0.0, apply_update=False)
+        res[mode] = (out, stats, net.get_grads().copy())
+        net.close()
+    for k in ("mu", "sigma", "vs"):
+        assert np.array_equal(res["on"][0][k], res["off"][0][k]), k
+    assert res["on"][1] == res["off"][1]
+    assert np.isfinite(res["on"][2]).all() and np.array_equal(res["on"][2], res["off"][2])
+    eng.close()
+
+
 def test_border_and_corner_agents_forward_and_gradients_match_oracle():
     """Hand-made observations that put agents on the corners, edges and last rows/columns of the 84x84 grid, several agents
     on ONE pixel, locusts piled on single bins and points outside the box (bin 255): the one-hot's conv1 cover is then

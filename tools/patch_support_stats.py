@@ -32,3 +32,9 @@ for it in range(26):
     if it % 5 == 0: print("after %d rollouts: slots/agent %.2f, support %.2f x %.2f pixels = %.1f %% of the 25; positions in the outer 8 pixels: %.1f %%"
           % (it + 1, (nr * nc).mean(), sr.mean(), sc.mean(), 100 * (sr * sc).mean() / 25,
              100 * ((pos < 8) | (pos > 75)).any(axis=1).mean()))
+
+# how many agents of an env stand on a pixel another agent of the same env already occupies (identical input image)?
+pos3 = eng.read("positions").reshape(E, 10, 2).astype(int)
+code = pos3[:, :, 0] * 84 + pos3[:, :, 1]
+dup = sum(10 - len(set(row.tolist())) for row in code)
+print("agents that duplicate another agent's pixel in their env: %.1f %%" % (100.0 * dup / (E * 10)))
