@@ -87,6 +87,12 @@ struct NetLane {
     unsigned *smask, *tmask, *zmask, *wmask;   // 25-bit patch support per sample / union per 128 sorted rows / per weight-gradient slice / slice union per sample
     int *slot_of;                      // sorted slot of a sample (inverse of perm)
     int2 *rowdesc;                     // gather descriptors of the compact slot rows (slot_rowdesc_kernel)
+    // tap-class order of the slot rows (slot_sort, net_shared.inc): key / rank / live-tap mask per row, sort scratch, sorted -> compact
+    // row, live-tap union per 256 sorted rows
+    unsigned char *skey;
+    unsigned short *srank, *stap;
+    int *sblkcnt, *sblkoff, *sbinbase, *sperm;
+    unsigned *stmask;
     int *sbase, *rowagent, *sblk;      // compact slot rows (net_shared.inc): prefix of per-sample slot counts, row -> sample, scan scratch
     signed char *tilegroup, *org;
     signed char *ulist;
@@ -686,6 +692,14 @@ static int alloc_lane_forward(grl_net *n) {
     if (rc == GRL_OK) rc = nalloc(n, &n->rowagent, c * 9);
     if (rc == GRL_OK) rc = nalloc(n, &n->rowdesc, c * 9);
     if (rc == GRL_OK) rc = nalloc(n, &n->sblk, 1024);
+    if (rc == GRL_OK) rc = nalloc(n, &n->skey, c * 9);
+    if (rc == GRL_OK) rc = nalloc(n, &n->srank, c * 9);
+    if (rc == GRL_OK) rc = nalloc(n, &n->stap, c * 9);
+    if (rc == GRL_OK) rc = nalloc(n, &n->sblkcnt, ((c * 9 + 1023) / 1024 + 1) * 25);
+    if (rc == GRL_OK) rc = nalloc(n, &n->sblkoff, ((c * 9 + 1023) / 1024 + 1) * 25);
+    if (rc == GRL_OK) rc = nalloc(n, &n->sbinbase, 32);
+    if (rc == GRL_OK) rc = nalloc(n, &n->sperm, c * 9 + 256);
+    if (rc == GRL_OK) rc = nalloc(n, &n->stmask, (c * 9 + 255) / 256 + 1);
     A(&n->carow, c * 128);
     if (rc == GRL_OK) rc = nalloc(n, &n->cperm, (size_t)n->ctiles * 256);
     if (rc == GRL_OK) rc = nalloc(n, &n->cblkcnt, ((c + 255) / 256) * 4);

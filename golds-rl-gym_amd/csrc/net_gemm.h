@@ -242,6 +242,37 @@ struct DenseRowsPair {
     __device__ __forceinline__ void mrange(int z, int mc, int &mbeg, int &mend) const { mbeg = z * mc; mend = min(rows, mbeg + mc); }
 };
 
+// The compact slot rows in TAP-CLASS order (net_shared.inc, slot_sort): a touched conv2 pixel u reaches conv3 outputs u - t, t in
+// 0..2, only inside 0..6, so a slot on the rim of the 9x9 map has 1, 2, 3, 4 or 6 live taps of the 9 (44 % are live on the bench
+// workload).  perm[s] = compact row (or -1 behind the live count), tmask[s >> 8] = the taps ANY of the 256 rows of a tile has live.
+// Forward (prod = d2s . W3f, N = 9 taps x 64): column tiles of dead taps are neither computed nor stored (n_ok); expand_conv3_patch
+// reads live taps only.
+struct SlotRowsP {
+    static constexpr bool kRelu = false;
+    const float *base;
+    const int *perm;
+    int rows, ld, k;
+    const int *rows_dev;
+    const unsigned *tmask;
+    __device__ __forceinline__ int K() const { return k; }
+    __device__ __forceinline__ void row(int r, long &off, int &iy0, int &ix0) const {
+        const int m = perm[r];
+        iy0 = m < 0 ? -1 : 0;
+        ix0 = 0;
+        off = (long)(m < 0 ? 0 : m) * ld;
+    }
+    __device__ __forceinline__ void tap(int k0, int &toff, int &ty, int &tx) const {
+        toff = k0;
+        ty = tx = 0;
+    }
+    __device__ __forceinline__ bool ok(int iy0, int, int, int) const { return iy0 >= 0; }
+    __device__ __forceinline__ bool tile_ok(int, int) const { return true; }
+    __device__ __forceinline__ bool tile_active(int m0) const { return m0 < *rows_dev; }
+    __device__ __forceinline__ bool n_ok(int m0, int n0) const { return !tmask || ((tmask[m0 >> 8] >> (n0 >> 6)) & 1u); }
+    __device__ __forceinline__ int bk(int k0, int) const { return k0; }
+    __device__ __forceinline__ int bn(int n0, int) const { return n0; }
+};
+
 // conv3's transposed convolution evaluated only at the <= 9 conv2 pixels ("slots") an agent's one-hot can reach: row r is one
 // slot with pixel u = ulist[r] of the 9x9 map; k = (ty, tx, co) reads dz3[n][uy-2+ty][ux-2+tx][co] like
 // ConvGather<9,9,1,1,-2,-2,3,3,64,7,7,true>.  The source is the patch-compact per-agent dz3 (net_patch.inc):

@@ -38,3 +38,16 @@ pos3 = eng.read("positions").reshape(E, 10, 2).astype(int)
 code = pos3[:, :, 0] * 84 + pos3[:, :, 1]
 dup = sum(10 - len(set(row.tolist())) for row in code)
 print("agents that duplicate another agent's pixel in their env: %.1f %%" % (100.0 * dup / (E * 10)))
+
+# conv3 slot rows: a touched conv2 pixel u reaches conv3 outputs u - t, t in 0..2, inside 0..6 only: which share of the 9 taps is live?
+def o2list(ph):
+    o1 = [o for o in range(20) if 4 * o <= ph <= 4 * o + 7]
+    return sorted({o for a in o1 for o in range(9) if 2 * o <= a <= 2 * o + 3})
+live = tot = 0
+pp = eng.read("positions").reshape(-1, 2).astype(int)
+tapsy = {p: [sum(1 for t in range(3) if 0 <= u - t <= 6) for u in o2list(p)] for p in range(84)}
+for ph, pw in pp[:20000]:
+    for ty in tapsy[ph]:
+        for tx in tapsy[pw]:
+            live += ty * tx; tot += 9
+print("live (slot, tap) pairs: %.1f %% of 9 per slot" % (100.0 * live / tot))
