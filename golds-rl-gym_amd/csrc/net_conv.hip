@@ -92,7 +92,7 @@ struct NetLane {
     unsigned char *skey;
     unsigned short *srank, *stap;
     int *sblkcnt, *sblkoff, *sbinbase, *sperm;
-    unsigned *stmask;
+    unsigned *stmask, *szmask;      // ... and per row range of the slot weight gradient (slot_wgrad_launch)
     int *sbase, *rowagent, *sblk;      // compact slot rows (net_shared.inc): prefix of per-sample slot counts, row -> sample, scan scratch
     signed char *tilegroup, *org;
     signed char *ulist;
@@ -128,6 +128,7 @@ struct grl_net : NetLane {
     int shared_trunk;
     // GEMM arithmetic: 0 = three fp16 products (operands must stay inside the fp16 range), 1 = v_mfma_f32_16x16x4_f32 (no range
     // limit, 103 instead of 200 TFLOP/s).  A pass that raised the range flag switches the net to 1 (range_fallback below).
+    double sfrac;              // likewise for the conv3 slot GEMMs: executed share of the 9 taps (per 256-row tile)
     double pfrac[3];           // executed share of the dense1 patch GEMMs' FLOPs in the last sorted chunk (profiling pass only; else 1)
     int patch_skip;            // 1: the dense1 patch GEMMs skip what the support masks say is zero (GRL_PATCH_SKIP=off: the plain 5x5 patch)
     int gemm_f32, range_fallback_on, range_fallbacks, range_bits_last, update_skipped_last;
@@ -700,6 +701,7 @@ static int alloc_lane_forward(grl_net *n) {
     if (rc == GRL_OK) rc = nalloc(n, &n->sbinbase, 32);
     if (rc == GRL_OK) rc = nalloc(n, &n->sperm, c * 9 + 256);
     if (rc == GRL_OK) rc = nalloc(n, &n->stmask, (c * 9 + 255) / 256 + 1);
+    if (rc == GRL_OK) rc = nalloc(n, &n->szmask, 1024);
     A(&n->carow, c * 128);
     if (rc == GRL_OK) rc = nalloc(n, &n->cperm, (size_t)n->ctiles * 256);
     if (rc == GRL_OK) rc = nalloc(n, &n->cblkcnt, ((c + 255) / 256) * 4);
@@ -784,7 +786,7 @@ int grl_net_create(grl_handle *h, const grl_net_config *cfg, grl_net **out) {
         n->range_fallbacks = 0; n->range_bits_last = 0; n->update_skipped_last = 0;
         const char *psk = getenv("GRL_PATCH_SKIP");
         n->patch_skip = (psk && strcmp(psk, "off") == 0) ? 0 : 1;
-        n->pfrac[0] = n->pfrac[1] = n->pfrac[2] = 1.0;
+        n->pfrac[0] = n->pfrac[1] = n->pfrac[2] = 1.0; n->sfrac = 1.0;
         const char *e2 = getenv("GRL_NET_EXPAND2");
         n->expand2_gemm = (e2 && strcmp(e2, "lds") == 0) ? 0 : 1;
     }

@@ -287,6 +287,11 @@ struct SlotGatherT3P {
                                  // so that the gather needs ONE index load per row instead of the chain row -> sample -> origin
     int rows;                    // upper bound (9 per sample); the live count is *rows_dev
     const int *rows_dev;
+    // Rows come in TAP-CLASS order (slot_sort, net_shared.inc): rowdesc[s] describes compact row perm[s]; tmask[s >> 8] = the taps
+    // any row of the 256-row tile has live (tile_ok skips the K-tiles of the others: their gathers are all zeros); zmask[z] = the
+    // same union over row range z of gemm_tn (i_ok: no slab tile; the slab reduction knows the same masks).  nullptr: no skipping.
+    const int *perm;
+    const unsigned *tmask, *zmask;
     __device__ __forceinline__ int K() const { return 576; }
     __device__ __forceinline__ void rowh(int2 d, long &off, int &iy0, int &ix0) const {
         off = d.x;
@@ -304,14 +309,16 @@ struct SlotGatherT3P {
     __device__ __forceinline__ bool ok(int iy0, int ix0, int ty, int tx) const {
         return (unsigned)(iy0 + ty) < 7u && (unsigned)(ix0 + tx) < 7u;
     }
-    __device__ __forceinline__ bool tile_ok(int, int) const { return true; }
+    // the masks are in the forward's tap numbering (output u - t); this gather's tap (ty, tx) reads output u - 2 + t: tap 8 - k there
+    __device__ __forceinline__ bool tile_ok(int m0, int k0) const { return !tmask || ((tmask[m0 >> 8] >> (8 - (k0 >> 6))) & 1u); }
     __device__ __forceinline__ bool tile_active(int m0) const { return m0 < *rows_dev; }
+    __device__ __forceinline__ bool i_ok(int z, int i0) const { return !zmask || ((zmask[z] >> (8 - (i0 >> 6))) & 1u); }
     __device__ __forceinline__ int bk(int k0, int) const { return k0; }
     __device__ __forceinline__ int bn(int n0, int) const { return n0; }
     // gemm_tn: row handles are fetched one tile ahead of the data (ahandle / bhandle may load), rowh is arithmetic only
     __device__ __forceinline__ int2 ahandle(int m) const { return rowdesc[m]; }
     __device__ __forceinline__ bool hvalid(int2) const { return true; }      // the offset of tap (0,0) may be negative
-    __device__ __forceinline__ int bhandle(int m) const { return m; }
+    __device__ __forceinline__ int bhandle(int m) const { return perm ? perm[m] : m; }      // the B operand's rows are the compact ones
     __device__ __forceinline__ void mrange(int z, int mc, int &mbeg, int &mend) const {
         mbeg = z * mc;
         mend = min(*rows_dev, mbeg + mc);
