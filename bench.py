@@ -450,7 +450,10 @@ def main():
                                "kernel": "gemm_rowk / gemm_tn (fp32 implicit GEMMs: operands split into 2 fp16 terms, "
                                          "3 v_mfma_f32_16x16x32_f16 per 16x16 tile and K=32 step, fp32 accumulation)",
                                "achieved": ach, "peak": MFMA_X3_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_X3_PEAK_TFLOPS,
-                               "peak_note": "achieved counts ALGORITHMIC fp32 FLOPs (2*M*N*K of the work actually executed); peak = "
+                               "peak_note": "achieved counts ALGORITHMIC fp32 FLOPs (2*M*N*K of the work actually executed: the dense1 patch "
+                                            "and conv3 slot GEMMs skip operand tiles that are exact zeros -- patch pixels / taps outside an "
+                                            "agent's conv3 footprint -- and are counted by their masks, so the fraction fell from 0.24 "
+                                            "when a fifth of the GEMM time went away with the FLOPs that ran fastest); peak = "
                                             "dense fp16 MFMA peak %.1f / %d fp16 products per fp32 product (round 2's six-product bf16 "
                                             "form had peak %.1f: halving the MFMA count doubled the peak this fraction is taken of).  "
                                             "The executed fp16 MFMA rate is %d x achieved; the fp32 MFMA peak "
