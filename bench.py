@@ -475,6 +475,13 @@ def main():
                                "by_family": {k: {"launches": v[0], "ms": v[1], "achieved": v[2] / (v[1] * 1e-3) / 1e12 if v[1] > 0 else 0.0,
                                                  "frac": (v[2] / (v[1] * 1e-3) / 1e12 / MFMA_X3_PEAK_TFLOPS) if v[1] > 0 else 0.0}
                                              for k, v in gemm_tags.items()}}
+            # what the support masks leave of the dense1 patch GEMMs: executed FLOPs against the plain 5x5 patch (2 * samples * 1600 * 512
+            # per launch of a chunk of min(E * 10, 81 920) samples)
+            chunk_samples = min(E * 10, 81920)
+            for fam in ("dense1_patch_fwd", "dense1_patch_dgrad", "dense1_patch_wgrad"):
+                if fam in gemm_tags and gemm_tags[fam][0] > 0:
+                    out["roofline"]["by_family"][fam]["executed_share_of_the_5x5_patch"] = \
+                        gemm_tags[fam][2] / (gemm_tags[fam][0] * 2.0 * chunk_samples * 1600 * 512)
             out["roofline_env_step"] = env_roof
         else:
             out["roofline"] = env_roof
