@@ -51,3 +51,27 @@ for ph, pw in pp[:20000]:
         for tx in tapsy[pw]:
             live += ty * tx; tot += 9
 print("live (slot, tap) pairs: %.1f %% of 9 per slot" % (100.0 * live / tot))
+
+# the shared trunk: how many of the 20x20 conv1 outputs of an env see any locust / agent bin at all (the rest are relu(bias))?
+lbn = eng.read("locust_bins").reshape(E, 80, 2).astype(int)
+abn = eng.read("agent_bins").reshape(E, 10, 2).astype(int)
+t1 = t2 = 0
+for e in range(0, E, 8):
+    pts = np.concatenate([lbn[e], abn[e]])
+    pts = pts[pts[:, 0] != 255]
+    touched = np.zeros((20, 20), bool)
+    for h, w in pts:
+        for oy in (h // 4, h // 4 - 1):
+            for ox in (w // 4, w // 4 - 1):
+                if 0 <= oy < 20 and 0 <= ox < 20 and h - 4 * oy < 8 and w - 4 * ox < 8:
+                    touched[oy, ox] = True
+    t1 += touched.sum()
+    o2 = np.zeros((9, 9), bool)
+    for oy, ox in zip(*np.nonzero(touched)):
+        for q in range(9):
+            for r in range(9):
+                if 0 <= oy - 2 * q < 4 and 0 <= ox - 2 * r < 4:
+                    o2[q, r] = True
+    t2 += o2.sum()
+ne = len(range(0, E, 8))
+print("shared trunk: conv1 outputs touched by any bin: %.1f of 400 per env; conv2 outputs that see a touched input: %.1f of 81" % (t1 / ne, t2 / ne))
