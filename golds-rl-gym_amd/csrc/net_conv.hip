@@ -92,6 +92,11 @@ struct NetLane {
     unsigned char *skey;
     unsigned short *srank, *stap;
     int *sblkcnt, *sblkoff, *sbinbase, *sperm;
+    // the shared trunk's affected conv2 rows (trunk_rows_kernel, net_shared.inc): 81-bit mask per env, row list + live count, the
+    // background image (b1 everywhere) and the background row's conv2 result (z then a, 64 each)
+    unsigned *tamask, *tbmask;      // + 100-bit mask of touched 2x2 conv1 pixel blocks, their list (rows of conv2's transposed convolution)
+    int *trowlist, *tblklist, *trows_n, *twgcnt, *twgoff;
+    float *tbgimg, *tbgz, *tslab, *tsums;      // tslab: per-workgroup sums of dz2 over unaffected rows; tsums: [dz2 total 64 | unaffected 64]
     unsigned *stmask, *szmask;      // ... and per row range of the slot weight gradient (slot_wgrad_launch)
     int *sbase, *rowagent, *sblk;      // compact slot rows (net_shared.inc): prefix of per-sample slot counts, row -> sample, scan scratch
     signed char *tilegroup, *org;
@@ -130,6 +135,7 @@ struct grl_net : NetLane {
     // limit, 103 instead of 200 TFLOP/s).  A pass that raised the range flag switches the net to 1 (range_fallback below).
     double sfrac;              // likewise for the conv3 slot GEMMs: executed share of the 9 taps (per 256-row tile)
     double pfrac[3];           // executed share of the dense1 patch GEMMs' FLOPs in the last sorted chunk (profiling pass only; else 1)
+    int trunk_skip;            // 1: conv2's forward / weight gradient / transposed convolution run over the rows the env's bins reach (GRL_TRUNK_SKIP=off: all rows)
     int patch_skip;            // 1: the dense1 patch GEMMs skip what the support masks say is zero (GRL_PATCH_SKIP=off: the plain 5x5 patch)
     int gemm_f32, range_fallback_on, range_fallbacks, range_bits_last, update_skipped_last;
     int loss_scale_on;         // per-pass power-of-two scale of the head gradients (net_train.inc); GRL_NET_LOSS_SCALE=off disables it
@@ -594,6 +600,7 @@ static int forward_chunk(grl_net *net, const uint8_t *lb, const uint8_t *ab, con
         int rc;
         if (reuse_tail && net->keep_level >= 2) {
             if ((rc = slot_index(net, pos, n))) return rc;
+            if (net->trunk_skip && net->expand2_gemm && (rc = trunk_index(net, lb, ab, pos, nenv))) return rc;      // the gradient step's row lists
             rc = patch_sort(net, n);
         } else {
             rc = forward_conv12_shared(net, lb, ab, pos, nenv);
@@ -702,6 +709,17 @@ static int alloc_lane_forward(grl_net *n) {
     if (rc == GRL_OK) rc = nalloc(n, &n->sperm, c * 9 + 256);
     if (rc == GRL_OK) rc = nalloc(n, &n->stmask, (c * 9 + 255) / 256 + 1);
     if (rc == GRL_OK) rc = nalloc(n, &n->szmask, 1024);
+    if (rc == GRL_OK) rc = nalloc(n, &n->tamask, (c / 10) * 3 + 3);
+    if (rc == GRL_OK) rc = nalloc(n, &n->tbmask, (c / 10) * 4 + 4);
+    if (rc == GRL_OK) rc = nalloc(n, &n->trowlist, (c / 10) * 81 + 256);
+    if (rc == GRL_OK) rc = nalloc(n, &n->tblklist, (c / 10) * 100 + 256);
+    if (rc == GRL_OK) rc = nalloc(n, &n->trows_n, 4);
+    if (rc == GRL_OK) rc = nalloc(n, &n->twgcnt, ((c / 10 + TRUNK_ENVS - 1) / TRUNK_ENVS + 1) * 2);
+    if (rc == GRL_OK) rc = nalloc(n, &n->twgoff, ((c / 10 + TRUNK_ENVS - 1) / TRUNK_ENVS + 1) * 2);
+    if (rc == GRL_OK) rc = nalloc(n, &n->tbgimg, 12800);
+    if (rc == GRL_OK) rc = nalloc(n, &n->tbgz, 128);
+    if (rc == GRL_OK) rc = nalloc(n, &n->tslab, 2048 * 64);
+    if (rc == GRL_OK) rc = nalloc(n, &n->tsums, 128);
     A(&n->carow, c * 128);
     if (rc == GRL_OK) rc = nalloc(n, &n->cperm, (size_t)n->ctiles * 256);
     if (rc == GRL_OK) rc = nalloc(n, &n->cblkcnt, ((c + 255) / 256) * 4);
@@ -786,6 +804,8 @@ int grl_net_create(grl_handle *h, const grl_net_config *cfg, grl_net **out) {
         n->range_fallbacks = 0; n->range_bits_last = 0; n->update_skipped_last = 0;
         const char *psk = getenv("GRL_PATCH_SKIP");
         n->patch_skip = (psk && strcmp(psk, "off") == 0) ? 0 : 1;
+        const char *tsk = getenv("GRL_TRUNK_SKIP");
+        n->trunk_skip = (tsk && strcmp(tsk, "off") == 0) ? 0 : 1;
         n->pfrac[0] = n->pfrac[1] = n->pfrac[2] = 1.0; n->sfrac = 1.0;
         const char *e2 = getenv("GRL_NET_EXPAND2");
         n->expand2_gemm = (e2 && strcmp(e2, "lds") == 0) ? 0 : 1;

@@ -110,6 +110,82 @@ struct ConvGather {
     __device__ __forceinline__ void mrange(int z, int mc, int &mbeg, int &mend) const { mbeg = z * mc; mend = min(rows, mbeg + mc); }
 };
 
+// conv2's forward over a ROW LIST (net_shared.inc, trunk_rows_kernel): only the (env, output) rows whose 4x4 window holds a conv1
+// pixel some bin touches are computed; every other row of the chunk is the same vector (conv2 of the constant relu(b1) image), which
+// one extra list entry (-1: the synthetic all-background image bg) computes with the same arithmetic and a fill kernel copies.
+struct GatherConv2ReluRows {
+    static constexpr bool kRelu = true;
+    const float *base;          // sraw[n][20][20][32]
+    const int *rowlist;         // row r -> env * 81 + output, or -1 for the background row
+    const int *rows_dev;        // live entries of rowlist
+    const float *bg;            // one 20 x 20 x 32 image of b1 (pre-activation of a pixel no bin touches)
+    int rows;                   // upper bound
+    __device__ __forceinline__ int K() const { return 512; }
+    __device__ __forceinline__ void row(int r, long &off, int &iy0, int &ix0) const {
+        const int q = r < *rows_dev ? rowlist[r] : -2;
+        iy0 = ix0 = 0;
+        off = 0;
+        if (q == -2) { iy0 = -1; return; }      // behind the list: zero row, not stored
+        const int n = q < 0 ? 0 : q / 81, o = q < 0 ? 0 : q - n * 81, qy = o / 9, qx = o - qy * 9;
+        off = (q < 0 ? (long)(bg - base) : (long)n * 12800) + ((long)(qy * 2) * 20 + qx * 2) * 32;
+    }
+    __device__ __forceinline__ void tap(int k0, int &toff, int &ty, int &tx) const {
+        const int t = k0 >> 5, c0 = k0 & 31;
+        ty = t >> 2;
+        tx = t & 3;
+        toff = (ty * 20 + tx) * 32 + c0;
+    }
+    __device__ __forceinline__ bool ok(int iy0, int, int, int) const { return iy0 >= 0; }
+    __device__ __forceinline__ bool tile_ok(int, int) const { return true; }
+    __device__ __forceinline__ bool tile_active(int m0) const { return m0 < *rows_dev; }
+    __device__ __forceinline__ int bk(int k0, int) const { return k0; }
+    __device__ __forceinline__ int bn(int n0, int) const { return n0; }
+    // gemm_tn (conv2's weight gradient over the affected rows; rows_dev then excludes the background entry): the live rows are
+    // dealt evenly to the nz row ranges of the launch, whatever their number turns out to be on the device
+    int nz;
+    __device__ __forceinline__ int2 ahandle(int m) const { return make_int2(rowlist[m], 0); }
+    __device__ __forceinline__ bool hvalid(int2 h) const { return h.x >= 0; }
+    __device__ __forceinline__ int bhandle(int m) const { return rowlist[m]; }
+    __device__ __forceinline__ void rowh(int2 h, long &off, int &iy0, int &ix0) const {
+        const int q = max(h.x, 0), n = q / 81, o = q - n * 81, qy = o / 9, qx = o - qy * 9;
+        iy0 = ix0 = 0;
+        off = (long)n * 12800 + ((long)(qy * 2) * 20 + qx * 2) * 32;
+    }
+    __device__ __forceinline__ void mrange(int z, int, int &mbeg, int &mend) const {
+        const int live = *rows_dev, per = ((live + nz - 1) / nz + 31) / 32 * 32;
+        mbeg = min(z * per, live);
+        mend = min(live, mbeg + per);
+    }
+};
+
+// conv2's transposed convolution (GatherT2) over a list of touched 2x2 pixel blocks: row r -> blklist[r] = env * 100 + block
+struct GatherT2Rows {
+    static constexpr bool kRelu = false;
+    const float *base;          // dz2[n][9][9][64]
+    const int *blklist, *rows_dev;
+    int rows;                   // upper bound
+    __device__ __forceinline__ int K() const { return 256; }
+    __device__ __forceinline__ void row(int r, long &off, int &iy0, int &ix0) const {
+        const int q = r < *rows_dev ? blklist[r] : -1;
+        if (q < 0) { iy0 = -64; ix0 = 0; off = 0; return; }      // behind the list: every tap invalid -> a zero row
+        const int n = q / 100, b = q - n * 100, qy = b / 10, qx = b - qy * 10;
+        iy0 = qy - 1;
+        ix0 = qx - 1;
+        off = (long)n * 5184 + ((long)iy0 * 9 + ix0) * 64;
+    }
+    __device__ __forceinline__ void tap(int k0, int &toff, int &ty, int &tx) const {
+        const int t = k0 >> 6, c0 = k0 & 63;
+        ty = t >> 1;
+        tx = t & 1;
+        toff = (ty * 9 + tx) * 64 + c0;
+    }
+    __device__ __forceinline__ bool ok(int iy0, int ix0, int ty, int tx) const { return (unsigned)(iy0 + ty) < 9u && (unsigned)(ix0 + tx) < 9u; }
+    __device__ __forceinline__ bool tile_ok(int, int) const { return true; }
+    __device__ __forceinline__ bool tile_active(int m0) const { return m0 < *rows_dev; }
+    __device__ __forceinline__ int bk(int k0, int) const { return k0; }
+    __device__ __forceinline__ int bn(int n0, int) const { return n0; }
+};
+
 // Pixel-major variant for stride-1 transposed convolutions: row r = q*nsamp + n (pixel q of sample n), so when
 // nsamp is a multiple of the M tile every row of a workgroup is the SAME pixel and the validity of a tap is
 // block-uniform: K-tiles whose tap falls outside the image are skipped instead of multiplied by zeros
@@ -461,6 +537,28 @@ struct EpiBiasDual {
     }
 };
 
+// EpiBiasDual over a row list (GatherConv2ReluRows): row r -> output row rowlist[r]; the background row (-1) goes to bgz / bga
+struct EpiBiasDualRows {
+    static constexpr bool kColSum = false, kAddAux = true;
+    float *C, *C2;
+    int ldc;
+    const float *bias;
+    const int *rowlist, *rows_dev;
+    float *bgz, *bga;
+    __device__ __forceinline__ int row_aux(int r) const { return r < *rows_dev ? rowlist[r] : -2; }
+    __device__ __forceinline__ float elem_aux(int, int c, int) const { return bias[c]; }
+    __device__ __forceinline__ void store(int, int c, float v, int q, float ea) const {
+        v += ea;
+        if (q >= 0) {
+            C[(long)q * ldc + c] = v;
+            C2[(long)q * ldc + c] = fmaxf(v, 0.f);
+        } else if (q == -1) {
+            bgz[c] = v;
+            bga[c] = fmaxf(v, 0.f);
+        }
+    }
+};
+
 // conv2 corrections (CorrRows): column block j = c >> 6 is the agent's canonical conv2 output j; cslot[m*9+j] = its compact slot
 // row (or -1).  On entry d2[slot] holds the env's shared PRE-activation of that pixel (conv2_prep_kernel copies it there); on exit
 // a2_a - a2sh = relu(z + v) - relu(z), plus one word of 64 channel sign bits of relu(z + v) per slot row.  The slot index is
@@ -583,14 +681,48 @@ struct EpiGradStride2 {
     __device__ __forceinline__ void store(int, int c, float v, int base, float ea) const { dX[(long)base + col_off(c)] = value(v, ea); }
 };
 
+// EpiGradStride2<true, true> over a block list (GatherT2Rows).  The column sums are taken RELATIVE to the background mask
+// m_bg[c] = (b1[c] > 0): sum over the listed pixels of (m - m_bg) . v -- what the untouched pixels (pre-activation b1, mask m_bg)
+// contribute to conv1's bias gradient is m_bg . (sum over ALL pixels of v), which has a closed form (trunk_closed_kernel).
+// elem_aux codes the two masks as 2 m + m_bg.
+struct EpiGradStride2Rows {
+    static constexpr bool kColSum = true;
+    float *dX;
+    const float *fwd;
+    float *csum;
+    const float *b1;
+    const int *blklist, *rows_dev;
+    __device__ __forceinline__ int row_aux(int r) const {
+        const int q = r < *rows_dev ? blklist[r] : -1;
+        if (q < 0) return -1;
+        const int n = q / 100, b = q - n * 100, yh = b / 10, xh = b - yh * 10;
+        return ((n * 20 + 2 * yh) * 20 + 2 * xh) * 32;
+    }
+    __device__ __forceinline__ int col_off(int col) const {
+        const int cls = col >> 5, c = col & 31;
+        return ((cls >> 1) * 20 + (cls & 1)) * 32 + c;
+    }
+    __device__ __forceinline__ float elem_aux(int, int c, int base) const {
+        const float s = fwd[(long)max(base, 0) + col_off(c)];
+        return (s > 0.f ? 2.f : 0.f) + (b1[c & 31] > 0.f ? 1.f : 0.f);
+    }
+    __device__ __forceinline__ float value(float v, float ea) const { return ea == 2.f ? v : ea == 1.f ? -v : 0.f; }
+    __device__ __forceinline__ void store(int, int c, float v, int base, float ea) const {
+        if (base >= 0) dX[(long)base + col_off(c)] = ea >= 2.f ? v : 0.f;
+    }
+};
+
 // c1b[c] += sum over wave tiles and the four classes of csum[tile][cls * 32 + c].  Two stages, both in a fixed order (bitwise
 // reproducible): kFoldParts workgroups each fold a contiguous range of wave tiles (8 strided partial sums per channel, combined in
 // order), then one wave adds the kFoldParts partial rows.  (A single workgroup walking all 6 400 tiles of a 4 096-env chunk took
 // 268 us per chunk -- 4.7 % of the update's kernel time.)
 constexpr int kFoldParts = 64;
-__global__ __launch_bounds__(256) void fold_class_sums_kernel(const float *__restrict__ csum, int parts, float *__restrict__ partial) {
+// live_rows != nullptr: the GEMM ran over a row list and wrote the tiles of its live rows only (two wave tiles per 128 rows)
+__global__ __launch_bounds__(256) void fold_class_sums_kernel(const float *__restrict__ csum, int parts, float *__restrict__ partial,
+                                                              const int *__restrict__ live_rows = nullptr) {
     __shared__ float red[256];
     const int c = threadIdx.x & 31, k = threadIdx.x >> 5;      // 8 partial sums per channel
+    if (live_rows) parts = min(parts, (*live_rows + 127) / 128 * 2);
     const int per = (parts + kFoldParts - 1) / kFoldParts, p0 = blockIdx.x * per, p1 = min(parts, p0 + per);
     float s = 0.f;
     for (int p = p0 + k; p < p1; p += 8) {

@@ -586,6 +586,59 @@ def test_patch_support_masks_change_nothing_but_the_work(monkeypatch):
     eng.close()
 
 
+def test_trunk_row_lists_change_nothing_but_the_work(monkeypatch):
+    """The env's shared trunk is mostly background: conv1 pixels no bin touches hold b1, conv2 outputs whose window sees none of the
+    touched pixels are one constant vector.  With GRL_TRUNK_SKIP (default) conv2's forward runs over the affected rows plus one
+    background row, its weight gradient over the affected rows plus a rank-1 term, its transposed convolution over the touched
+    pixel blocks, and conv1's bias gradient takes the background's part in closed form (net_shared.inc).  Forward: the same bits.
+    Gradient: the same sums in another association -- 2e-6 of each block's largest entry.  Non-zero biases (the background terms
+    vanish with b1 = 0), envs from crowded to empty (every locust outside the box), ragged chunks."""
+    from goldsrl import _ffi, _ffi_net
+    E = 90
+    eng = _ffi.Engine(_ffi.ENV_SWARM, E, seed=3)
+    eng.reset()
+    rng = np.random.RandomState(15)
+    lb = rng.randint(0, 84, size=(E, 80, 2)).astype(np.uint8)
+    pos = rng.randint(0, 84, size=(E, 10, 2)).astype(np.uint8)
+    for e in range(E):
+        if e % 3 == 0:        # locusts crowded into a corner region: few touched pixels
+            lb[e] = rng.randint(0, 12, size=(80, 2))
+        if e % 7 == 0:        # all locusts outside the box, two agents too
+            lb[e] = 255
+            pos[e, :2] = 255
+        if e % 5 == 0:        # agents on the rim
+            pos[e, 2:6, 0] = rng.choice([0, 1, 82, 83], size=4)
+    ab = pos.copy()
+    act, adv, y = _train_inputs(E, seed=16)
+    flat = _ffi_net.glorot_uniform_flat(seed=17).astype(np.float64)
+    p = NN.unflatten_params(flat)
+    for k in p:
+        if k.endswith("_b"):
+            p[k] = rng.normal(size=p[k].shape) * 0.05
+    flat = NN.flatten_params(p).astype(np.float32)
+    res = {}
+    for mode in ("on", "off"):
+        monkeypatch.setenv("GRL_TRUNK_SKIP", mode)      # read when the net is created
+        net = _ffi_net.ConvNet(eng, max_chunk_samples=370)
+        net.set_params(flat)
+        out = net.predict_obs(lb, ab, pos)
+        stats = net.train_obs(lb, ab, pos, act, adv, y, lr=0.0, apply_update=False)
+        g1 = net.get_grads().copy()
+        net.train_obs(lb, ab, pos, act, adv, y, lr=0.0, apply_update=False)
+        assert np.array_equal(g1, net.get_grads()), "gradient not reproducible (%s)" % mode
+        res[mode] = (out, stats, g1)
+        net.close()
+    for k in ("mu", "sigma", "vs"):
+        assert np.array_equal(res["on"][0][k], res["off"][0][k]), k
+    np.testing.assert_allclose(list(res["on"][1].values()), list(res["off"][1].values()), rtol=1e-6)
+    gon, goff = NN.unflatten_params(res["on"][2].astype(np.float64)), NN.unflatten_params(res["off"][2].astype(np.float64))
+    for k in gon:
+        scale = np.abs(goff[k]).max()
+        assert scale > 0, k
+        assert np.abs(gon[k] - goff[k]).max() <= 2e-6 * scale, (k, np.abs(gon[k] - goff[k]).max() / scale)
+    eng.close()
+
+
 def test_border_and_corner_agents_forward_and_gradients_match_oracle():
     """Hand-made observations that put agents on the corners, edges and last rows/columns of the 84x84 grid, several agents
     on ONE pixel, locusts piled on single bins and points outside the box (bin 255): the one-hot's conv1 cover is then
