@@ -92,11 +92,10 @@ struct NetLane {
     unsigned char *skey;
     unsigned short *srank, *stap;
     int *sblkcnt, *sblkoff, *sbinbase, *sperm;
-    // the shared trunk's affected conv2 rows (trunk_rows_kernel, net_shared.inc): 81-bit mask per env, row list + live count, the
-    // background image (b1 everywhere) and the background row's conv2 result (z then a, 64 each)
-    unsigned *tamask, *tbmask;      // + 100-bit mask of touched 2x2 conv1 pixel blocks, their list (rows of conv2's transposed convolution)
-    int *trowlist, *tblklist, *trows_n, *twgcnt, *twgoff;
-    float *tbgimg, *tbgz, *tslab, *tsums;      // tslab: per-workgroup sums of dz2 over unaffected rows; tsums: [dz2 total 64 | unaffected 64]
+    // the shared trunk's affected conv2 rows (trunk_index, net_shared.inc): 81-bit mask per env, row list + live count
+    unsigned *tamask, *tbmask, *tcmask;      // + 100-bit mask of touched 2x2 conv1 pixel blocks, 49-bit mask of affected conv3 outputs
+    int *trowlist, *tblklist, *tc3list, *trows_n, *twgcnt, *twgoff;      // their lists, live counts [conv2 rows, blocks, conv3 rows], scan scratch
+    float *tslab, *tsums;      // tslab: per-workgroup sums of dz2 over unaffected rows; tsums: [dz2 total 64 | unaffected 64]
     unsigned *stmask, *szmask;      // ... and per row range of the slot weight gradient (slot_wgrad_launch)
     int *sbase, *rowagent, *sblk;      // compact slot rows (net_shared.inc): prefix of per-sample slot counts, row -> sample, scan scratch
     signed char *tilegroup, *org;
@@ -135,6 +134,10 @@ struct grl_net : NetLane {
     // limit, 103 instead of 200 TFLOP/s).  A pass that raised the range flag switches the net to 1 (range_fallback below).
     double sfrac;              // likewise for the conv3 slot GEMMs: executed share of the 9 taps (per 256-row tile)
     double pfrac[3];           // executed share of the dense1 patch GEMMs' FLOPs in the last sorted chunk (profiling pass only; else 1)
+    // the background's way through the trunk (trunk_background, net_shared.inc; per parameter version): the all-b1 image, [z2 | a2] of
+    // its conv2 row, a2 at all 81 pixels, [z3 | a3] of its conv3 row, the one-row list of those passes
+    float *tbgimg, *tbgz, *tbgimg3, *tbgz3;
+    int *tbglist;
     int trunk_skip;            // 1: conv2's forward / weight gradient / transposed convolution run over the rows the env's bins reach (GRL_TRUNK_SKIP=off: all rows)
     int patch_skip;            // 1: the dense1 patch GEMMs skip what the support masks say is zero (GRL_PATCH_SKIP=off: the plain 5x5 patch)
     int gemm_f32, range_fallback_on, range_fallbacks, range_bits_last, update_skipped_last;
@@ -314,6 +317,7 @@ __global__ void transpose_kernel(const float *__restrict__ src, int K, int N, fl
 
 __global__ void conv2_corr_weights_kernel(const float *__restrict__ w2, float *__restrict__ bt);      // net_shared.inc
 // keep paramsT in step with params (after set_params, Adam, broadcast)
+static int trunk_background(grl_net *net);      // net_shared.inc
 static void refresh_transposes(grl_net *net) {
     const struct { long off; int K, N; } L[] = {
         {ConvOffsets::c2w, 512, 64}, {ConvOffsets::c3w, 576, 64}, {ConvOffsets::d1w, 3136, 512}, {ConvOffsets::d2w, 512, 256},
@@ -326,6 +330,7 @@ static void refresh_transposes(grl_net *net) {
     for (int tap = 0; tap < 9; ++tap)     // w3f[(tap, co)][ci]: each tap's 64x64 block transposed
         hipLaunchKernelGGL(transpose_kernel, dim3(2, 2), dim3(32, 8), 0, net->h->stream, net->params + ConvOffsets::c3w + tap * 4096, 64, 64,
                            net->w3f + tap * 4096);
+    (void)trunk_background(net);
 }
 
 // ------------------------------------------------------------------------------------------ conv1 (sparse)
@@ -711,15 +716,15 @@ static int alloc_lane_forward(grl_net *n) {
     if (rc == GRL_OK) rc = nalloc(n, &n->szmask, 1024);
     if (rc == GRL_OK) rc = nalloc(n, &n->tamask, (c / 10) * 3 + 3);
     if (rc == GRL_OK) rc = nalloc(n, &n->tbmask, (c / 10) * 4 + 4);
+    if (rc == GRL_OK) rc = nalloc(n, &n->tcmask, (c / 10) * 2 + 2);
     if (rc == GRL_OK) rc = nalloc(n, &n->trowlist, (c / 10) * 81 + 256);
     if (rc == GRL_OK) rc = nalloc(n, &n->tblklist, (c / 10) * 100 + 256);
+    if (rc == GRL_OK) rc = nalloc(n, &n->tc3list, (c / 10) * 49 + 256);
     if (rc == GRL_OK) rc = nalloc(n, &n->trows_n, 4);
-    if (rc == GRL_OK) rc = nalloc(n, &n->twgcnt, ((c / 10 + TRUNK_ENVS - 1) / TRUNK_ENVS + 1) * 2);
-    if (rc == GRL_OK) rc = nalloc(n, &n->twgoff, ((c / 10 + TRUNK_ENVS - 1) / TRUNK_ENVS + 1) * 2);
-    if (rc == GRL_OK) rc = nalloc(n, &n->tbgimg, 12800);
-    if (rc == GRL_OK) rc = nalloc(n, &n->tbgz, 128);
-    if (rc == GRL_OK) rc = nalloc(n, &n->tslab, 2048 * 64);
-    if (rc == GRL_OK) rc = nalloc(n, &n->tsums, 128);
+    if (rc == GRL_OK) rc = nalloc(n, &n->twgcnt, ((c / 10 + TRUNK_ENVS - 1) / TRUNK_ENVS + 1) * 3);
+    if (rc == GRL_OK) rc = nalloc(n, &n->twgoff, ((c / 10 + TRUNK_ENVS - 1) / TRUNK_ENVS + 1) * 3);
+    if (rc == GRL_OK) rc = nalloc(n, &n->tslab, 2 * 2048 * 64);
+    if (rc == GRL_OK) rc = nalloc(n, &n->tsums, 256);
     A(&n->carow, c * 128);
     if (rc == GRL_OK) rc = nalloc(n, &n->cperm, (size_t)n->ctiles * 256);
     if (rc == GRL_OK) rc = nalloc(n, &n->cblkcnt, ((c + 255) / 256) * 4);
@@ -824,6 +829,8 @@ int grl_net_create(grl_handle *h, const grl_net_config *cfg, grl_net **out) {
     auto A = [&](float **p, size_t cnt) { if (rc == GRL_OK) rc = nalloc(n, p, cnt); };
     A(&n->params, n->ho.total); A(&n->paramsT, n->ho.total); A(&n->adam_m, n->ho.total); A(&n->adam_v, n->ho.total);
     A(&n->w3f, 576 * 64); A(&n->stats, 16); A(&n->w2corr, 4 * 576 * 128);
+    A(&n->tbgimg, 12800); A(&n->tbgz, 128); A(&n->tbgimg3, 5184); A(&n->tbgz3, 128);
+    if (rc == GRL_OK) rc = nalloc(n, &n->tbglist, 4);
     int nlanes = (cfg->reserved & GRL_NET_F_SINGLE_STREAM) ? 1 : 4;      // measured at 32 768 envs: 1.41 / 1.22 / 1.16 / 1.13 / 1.14 s per update with 1 / 2 / 3 / 4 / 8
     if (const char *env = getenv("GRL_NET_LANES")) { int v = atoi(env); if (v >= 1 && v <= GRL_MAX_LANES) nlanes = v; }      // tuning knob
     for (int k = 0; k < nlanes && rc == GRL_OK; ++k) {       // lane k's forward workspace (allocated into *n, then parked)
@@ -961,6 +968,7 @@ static bool range_fall_back(grl_net *n) {
     if (!n->range_fallback_on || n->gemm_f32) return false;
     n->gemm_f32 = 1;
     n->range_fallbacks += 1;
+    (void)trunk_background(n);      // the background rows in the arithmetic the list GEMMs now use
     return true;
 }
 
@@ -1019,7 +1027,7 @@ int grl_net_set_gemm_f32(grl_net *n, int32_t on) {
     hipSetDevice(n->h->cfg.device_id);
     NET_HIP(n, hipStreamSynchronize(n->h->stream));
     n->gemm_f32 = on ? 1 : 0;
-    return GRL_OK;
+    return trunk_background(n);
 }
 
 static int read_activation_impl(grl_net *n, const char *which, float *host, size_t bytes);

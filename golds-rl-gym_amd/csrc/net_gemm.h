@@ -110,46 +110,51 @@ struct ConvGather {
     __device__ __forceinline__ void mrange(int z, int mc, int &mbeg, int &mend) const { mbeg = z * mc; mend = min(rows, mbeg + mc); }
 };
 
-// conv2's forward over a ROW LIST (net_shared.inc, trunk_rows_kernel): only the (env, output) rows whose 4x4 window holds a conv1
-// pixel some bin touches are computed; every other row of the chunk is the same vector (conv2 of the constant relu(b1) image), which
-// one extra list entry (-1: the synthetic all-background image bg) computes with the same arithmetic and a fill kernel copies.
-struct GatherConv2ReluRows {
-    static constexpr bool kRelu = true;
-    const float *base;          // sraw[n][20][20][32]
-    const int *rowlist;         // row r -> env * 81 + output, or -1 for the background row
+// A convolution's forward / weight-gradient operand over a ROW LIST (net_shared.inc, trunk_index): only the (env, output) rows whose
+// window holds an input pixel that differs from the env's background are computed; every other row of the chunk is the same vector
+// (the layer applied to the constant background image), which one extra list entry (-1: the synthetic background image bg) computes
+// with the same arithmetic and a fill kernel copies.  OW outputs per side, input image IW x IW x C, stride S, P x P taps.
+template <int OW, int IW, int C, int S, int P, bool RELU>
+struct ConvRowsList {
+    static constexpr bool kRelu = RELU;
+    static constexpr int kOut = OW * OW, kImg = IW * IW * C;
+    const float *base;          // input [n][IW][IW][C]
+    const int *rowlist;         // row r -> env * kOut + output, or -1 for the background row
     const int *rows_dev;        // live entries of rowlist
-    const float *bg;            // one 20 x 20 x 32 image of b1 (pre-activation of a pixel no bin touches)
+    const float *bg;            // one background image
     int rows;                   // upper bound
-    __device__ __forceinline__ int K() const { return 512; }
+    int nz;                     // gemm_tn: row ranges of the launch
+    __device__ __forceinline__ int K() const { return P * P * C; }
+    __device__ __forceinline__ long off_of(int q) const {
+        const int n = q < 0 ? 0 : q / kOut, o = q < 0 ? 0 : q - n * kOut, qy = o / OW, qx = o - qy * OW;
+        return (q < 0 ? (long)(bg - base) : (long)n * kImg) + ((long)(qy * S) * IW + qx * S) * C;
+    }
     __device__ __forceinline__ void row(int r, long &off, int &iy0, int &ix0) const {
         const int q = r < *rows_dev ? rowlist[r] : -2;
         iy0 = ix0 = 0;
         off = 0;
         if (q == -2) { iy0 = -1; return; }      // behind the list: zero row, not stored
-        const int n = q < 0 ? 0 : q / 81, o = q < 0 ? 0 : q - n * 81, qy = o / 9, qx = o - qy * 9;
-        off = (q < 0 ? (long)(bg - base) : (long)n * 12800) + ((long)(qy * 2) * 20 + qx * 2) * 32;
+        off = off_of(q);
     }
     __device__ __forceinline__ void tap(int k0, int &toff, int &ty, int &tx) const {
-        const int t = k0 >> 5, c0 = k0 & 31;
-        ty = t >> 2;
-        tx = t & 3;
-        toff = (ty * 20 + tx) * 32 + c0;
+        const int t = k0 / C, c0 = k0 - t * C;
+        ty = t / P;
+        tx = t - ty * P;
+        toff = (ty * IW + tx) * C + c0;
     }
     __device__ __forceinline__ bool ok(int iy0, int, int, int) const { return iy0 >= 0; }
     __device__ __forceinline__ bool tile_ok(int, int) const { return true; }
     __device__ __forceinline__ bool tile_active(int m0) const { return m0 < *rows_dev; }
     __device__ __forceinline__ int bk(int k0, int) const { return k0; }
     __device__ __forceinline__ int bn(int n0, int) const { return n0; }
-    // gemm_tn (conv2's weight gradient over the affected rows; rows_dev then excludes the background entry): the live rows are
+    // gemm_tn (the layer's weight gradient over the affected rows; rows_dev then excludes the background entry): the live rows are
     // dealt evenly to the nz row ranges of the launch, whatever their number turns out to be on the device
-    int nz;
     __device__ __forceinline__ int2 ahandle(int m) const { return make_int2(rowlist[m], 0); }
     __device__ __forceinline__ bool hvalid(int2 h) const { return h.x >= 0; }
     __device__ __forceinline__ int bhandle(int m) const { return rowlist[m]; }
     __device__ __forceinline__ void rowh(int2 h, long &off, int &iy0, int &ix0) const {
-        const int q = max(h.x, 0), n = q / 81, o = q - n * 81, qy = o / 9, qx = o - qy * 9;
         iy0 = ix0 = 0;
-        off = (long)n * 12800 + ((long)(qy * 2) * 20 + qx * 2) * 32;
+        off = off_of(max(h.x, 0));
     }
     __device__ __forceinline__ void mrange(int z, int, int &mbeg, int &mend) const {
         const int live = *rows_dev, per = ((live + nz - 1) / nz + 31) / 32 * 32;
@@ -157,6 +162,8 @@ struct GatherConv2ReluRows {
         mend = min(live, mbeg + per);
     }
 };
+using GatherConv2ReluRows = ConvRowsList<9, 20, 32, 2, 4, true>;      // relu(sraw)[n][20][20][32] -> rows (n, o2), K = 512
+using GatherConv3Rows = ConvRowsList<7, 9, 64, 1, 3, false>;           // a2sh[n][9][9][64] -> rows (n, o3), K = 576
 
 // conv2's transposed convolution (GatherT2) over a list of touched 2x2 pixel blocks: row r -> blklist[r] = env * 100 + block
 struct GatherT2Rows {
@@ -551,8 +558,8 @@ struct EpiBiasDualRows {
         v += ea;
         if (q >= 0) {
             C[(long)q * ldc + c] = v;
-            C2[(long)q * ldc + c] = fmaxf(v, 0.f);
-        } else if (q == -1) {
+            if (C2) C2[(long)q * ldc + c] = fmaxf(v, 0.f);      // conv3 stores the pre-activation only
+        } else if (q == -1 && bgz) {
             bgz[c] = v;
             bga[c] = fmaxf(v, 0.f);
         }

@@ -55,7 +55,7 @@ print("live (slot, tap) pairs: %.1f %% of 9 per slot" % (100.0 * live / tot))
 # the shared trunk: how many of the 20x20 conv1 outputs of an env see any locust / agent bin at all (the rest are relu(bias))?
 lbn = eng.read("locust_bins").reshape(E, 80, 2).astype(int)
 abn = eng.read("agent_bins").reshape(E, 10, 2).astype(int)
-t1 = t2 = 0
+t1 = t2 = t3 = inbox = ubins = 0
 for e in range(0, E, 8):
     pts = np.concatenate([lbn[e], abn[e]])
     pts = pts[pts[:, 0] != 255]
@@ -73,5 +73,13 @@ for e in range(0, E, 8):
                 if 0 <= oy - 2 * q < 4 and 0 <= ox - 2 * r < 4:
                     o2[q, r] = True
     t2 += o2.sum()
+    o3 = np.zeros((7, 7), bool)
+    for q, r in zip(*np.nonzero(o2)):
+        o3[max(q - 2, 0):min(q, 6) + 1, max(r - 2, 0):min(r, 6) + 1] = True
+    t3 += o3.sum()
+    inbox += len(pts)
+    ubins += len({(h, w) for h, w in pts})
 ne = len(range(0, E, 8))
+print("points inside the box: %.1f of 90 per env, distinct bins %.1f; conv3 outputs that see an affected conv2 output: %.1f of 49"
+      % (inbox / ne, ubins / ne, t3 / ne))
 print("shared trunk: conv1 outputs touched by any bin: %.1f of 400 per env; conv2 outputs that see a touched input: %.1f of 81" % (t1 / ne, t2 / ne))
