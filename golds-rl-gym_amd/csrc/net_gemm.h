@@ -165,6 +165,34 @@ struct ConvRowsList {
 using GatherConv2ReluRows = ConvRowsList<9, 20, 32, 2, 4, true>;      // relu(sraw)[n][20][20][32] -> rows (n, o2), K = 512
 using GatherConv3Rows = ConvRowsList<7, 9, 64, 1, 3, false>;           // a2sh[n][9][9][64] -> rows (n, o3), K = 576
 
+// conv3's transposed convolution (GatherT3) over the list of affected conv2 rows: row r -> rowlist[r] = env * 81 + pixel
+struct GatherT3Rows {
+    static constexpr bool kRelu = false;
+    const float *base;          // dz3[n][7][7][64]
+    const int *rowlist, *rows_dev;
+    int rows;                   // upper bound
+    __device__ __forceinline__ int K() const { return 576; }
+    __device__ __forceinline__ void row(int r, long &off, int &iy0, int &ix0) const {
+        const int q = r < *rows_dev ? rowlist[r] : -1;
+        if (q < 0) { iy0 = -64; ix0 = 0; off = 0; return; }      // behind the list: every tap invalid -> a zero row
+        const int n = q / 81, o = q - n * 81, qy = o / 9, qx = o - qy * 9;
+        iy0 = qy - 2;
+        ix0 = qx - 2;
+        off = (long)n * 3136 + ((long)iy0 * 7 + ix0) * 64;
+    }
+    __device__ __forceinline__ void tap(int k0, int &toff, int &ty, int &tx) const {
+        const int t = k0 >> 6, c0 = k0 & 63;
+        ty = t / 3;
+        tx = t - ty * 3;
+        toff = (ty * 7 + tx) * 64 + c0;
+    }
+    __device__ __forceinline__ bool ok(int iy0, int ix0, int ty, int tx) const { return (unsigned)(iy0 + ty) < 7u && (unsigned)(ix0 + tx) < 7u; }
+    __device__ __forceinline__ bool tile_ok(int, int) const { return true; }
+    __device__ __forceinline__ bool tile_active(int m0) const { return m0 < *rows_dev; }
+    __device__ __forceinline__ int bk(int k0, int) const { return k0; }
+    __device__ __forceinline__ int bn(int n0, int) const { return n0; }
+};
+
 // conv2's transposed convolution (GatherT2) over a list of touched 2x2 pixel blocks: row r -> blklist[r] = env * 100 + block
 struct GatherT2Rows {
     static constexpr bool kRelu = false;
@@ -686,6 +714,23 @@ struct EpiGradStride2 {
     __device__ __forceinline__ float elem_aux(int, int c, int base) const { return MASK ? fwd[(long)base + col_off(c)] : 0.f; }
     __device__ __forceinline__ float value(float v, float ea) const { return (!MASK || ea > 0.f) ? v : 0.f; }
     __device__ __forceinline__ void store(int, int c, float v, int base, float ea) const { dX[(long)base + col_off(c)] = value(v, ea); }
+};
+
+// EpiGrad over a row list (GatherT3Rows): dX[q][c] = v * (fwd[q][c] > 0) at the listed rows q; the column sums are those of the
+// UNMASKED v over the listed rows (per wave tile; trunk_closed3_kernel turns them into the unlisted rows' sum)
+struct EpiGradRowsSum {
+    static constexpr bool kColSum = true;
+    float *dX;
+    int ld;
+    const float *fwd;
+    float *csum;
+    const int *rowlist, *rows_dev;
+    __device__ __forceinline__ int row_aux(int r) const { return r < *rows_dev ? rowlist[r] : -1; }
+    __device__ __forceinline__ float elem_aux(int, int c, int q) const { return fwd[(long)max(q, 0) * ld + c]; }
+    __device__ __forceinline__ float value(float v, float) const { return v; }
+    __device__ __forceinline__ void store(int, int c, float v, int q, float ea) const {
+        if (q >= 0) dX[(long)q * ld + c] = ea > 0.f ? v : 0.f;
+    }
 };
 
 // EpiGradStride2<true, true> over a block list (GatherT2Rows).  The column sums are taken RELATIVE to the background mask
