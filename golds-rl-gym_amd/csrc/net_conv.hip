@@ -93,7 +93,7 @@ struct NetLane {
     unsigned short *srank, *stap;
     int *sblkcnt, *sblkoff, *sbinbase, *sperm;
     // the shared trunk's affected conv2 rows (trunk_index, net_shared.inc): 81-bit mask per env, row list + live count
-    unsigned *tamask, *tbmask, *tcmask;      // + 100-bit mask of touched 2x2 conv1 pixel blocks, 49-bit mask of affected conv3 outputs
+    unsigned *tamask, *tbmask, *tcmask, *tnmask;      // (tnmask: blocks of sraw anybody reads) + 100-bit mask of touched 2x2 conv1 pixel blocks, 49-bit mask of affected conv3 outputs
     int *trowlist, *tblklist, *tc3list, *trows_n, *twgcnt, *twgoff;      // their lists, live counts [conv2 rows, blocks, conv3 rows], scan scratch
     float *tslab, *tsums;      // tslab: per-workgroup sums of dz2 over unaffected rows; tsums: [dz2 total 64 | unaffected 64]
     unsigned *stmask, *szmask;      // ... and per row range of the slot weight gradient (slot_wgrad_launch)
@@ -411,9 +411,11 @@ __global__ __launch_bounds__(256) void conv1_sparse_kernel(const uint8_t *__rest
 // share a CU instead of two.  Same sums in the same order as conv1_sparse_kernel (bit-identical output).
 __global__ __launch_bounds__(256) void conv1_sparse_shared_kernel(const uint8_t *__restrict__ lbins, const uint8_t *__restrict__ abins,
                                                                   const float *__restrict__ w1, const float *__restrict__ b1, int G,
-                                                                  float *__restrict__ sraw) {
+                                                                  float *__restrict__ sraw, const unsigned *__restrict__ nmask) {
     __shared__ unsigned int cnt[2][7056 / 4 + 4];   // 84x84 byte counters per channel, packed 4 per word
+    __shared__ unsigned need[4];                    // 2 x 2 pixel blocks anybody reads (trunk_mark_kernel); nmask == nullptr: all
     const int env = blockIdx.x, tid = threadIdx.x;
+    if (tid < 4) need[tid] = nmask ? nmask[(size_t)env * 4 + tid] : 0xFFFFFFFFu;
     for (int i = tid; i < 2 * (7056 / 4 + 4); i += 256) (&cnt[0][0])[i] = 0;
     __syncthreads();
     if (tid < 80) {
@@ -428,7 +430,8 @@ __global__ __launch_bounds__(256) void conv1_sparse_shared_kernel(const uint8_t 
     float4 *out = reinterpret_cast<float4 *>(sraw + (size_t)env * 12800);
     for (int item = tid; item < 1600; item += 256) {
         const int pix = item >> 2, c0 = (item & 3) * 8;
-        const int oy = pix / 20, ox = pix - oy * 20;
+        const int oy = pix / 20, ox = pix - oy * 20, blk = (oy >> 1) * 10 + (ox >> 1);
+        if (!((need[blk >> 5] >> (blk & 31)) & 1u)) continue;
         float acc[8];
 #pragma unroll
         for (int co = 0; co < 8; ++co) acc[co] = b1[c0 + co];
@@ -717,6 +720,7 @@ static int alloc_lane_forward(grl_net *n) {
     if (rc == GRL_OK) rc = nalloc(n, &n->tamask, (c / 10) * 3 + 3);
     if (rc == GRL_OK) rc = nalloc(n, &n->tbmask, (c / 10) * 4 + 4);
     if (rc == GRL_OK) rc = nalloc(n, &n->tcmask, (c / 10) * 2 + 2);
+    if (rc == GRL_OK) rc = nalloc(n, &n->tnmask, (c / 10) * 4 + 4);
     if (rc == GRL_OK) rc = nalloc(n, &n->trowlist, (c / 10) * 81 + 256);
     if (rc == GRL_OK) rc = nalloc(n, &n->tblklist, (c / 10) * 100 + 256);
     if (rc == GRL_OK) rc = nalloc(n, &n->tc3list, (c / 10) * 49 + 256);
@@ -1050,6 +1054,8 @@ static int read_activation_impl(grl_net *n, const char *which, float *host, size
     else if (w == "a1sh" || w == "sraw") {     // per ENV: (n/10, 20, 20, 32)
         size_t need_e = (size_t)(n->last_n / 10) * 12800 * 4;
         if (bytes != need_e) return nfail(n, GRL_E_SIZE, "grl_net_read_activation: need " + std::to_string(need_e) + " bytes");
+        if (n->trunk_skip && n->expand2_gemm)      // list form: the blocks nobody reads were not written; they hold b1 (debug/test access)
+            hipLaunchKernelGGL(materialize_sraw_kernel, dim3(n->last_n / 10), dim3(256), 0, n->h->stream, n->tnmask, n->params + ConvOffsets::c1b, n->sraw);
         NET_HIP(n, hipStreamSynchronize(n->h->stream));
         NET_HIP(n, hipMemcpy(host, n->sraw, bytes, hipMemcpyDeviceToHost));
         if (w == "a1sh") {     // relu(sraw): not materialised on the device
