@@ -452,8 +452,10 @@ def main():
                                "achieved": ach, "peak": MFMA_X3_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_X3_PEAK_TFLOPS,
                                "peak_note": "achieved counts ALGORITHMIC fp32 FLOPs (2*M*N*K of the work actually executed: the dense1 patch "
                                             "and conv3 slot GEMMs skip operand tiles that are exact zeros -- patch pixels / taps outside an "
-                                            "agent's conv3 footprint -- and are counted by their masks, so the fraction fell from 0.24 "
-                                            "when a fifth of the GEMM time went away with the FLOPs that ran fastest); peak = "
+                                            "agent's conv3 footprint -- and the env-level conv2 / conv3 GEMMs run over the rows the env's "
+                                            "bins reach, the constant background rows entering in closed form; all counted by their masks / "
+                                            "live row counts, so the fraction fell from 0.24 when the GEMM time shrank with the FLOPs that "
+                                            "ran fastest; `contract` prices the same update by SURVEY 8(d)'s per-agent figure); peak = "
                                             "dense fp16 MFMA peak %.1f / %d fp16 products per fp32 product (round 2's six-product bf16 "
                                             "form had peak %.1f: halving the MFMA count doubled the peak this fraction is taken of).  "
                                             "The executed fp16 MFMA rate is %d x achieved; the fp32 MFMA peak "
@@ -475,6 +477,16 @@ def main():
                                "by_family": {k: {"launches": v[0], "ms": v[1], "achieved": v[2] / (v[1] * 1e-3) / 1e12 if v[1] > 0 else 0.0,
                                                  "frac": (v[2] / (v[1] * 1e-3) / 1e12 / MFMA_X3_PEAK_TFLOPS) if v[1] > 0 else 0.0}
                                              for k, v in gemm_tags.items()}}
+            # SURVEY 8(d)'s algorithmic figure: the reference evaluates the net once per agent-sample, 18.10 MFLOP forward, backward = 2x
+            # forward; an update = (T + 1) rollout forwards + T training forwards and backwards over E * 10 agent-samples
+            contract_flops = 18.10e6 * 10 * E * ((T + 1) + (0 if args.no_train else 3 * T))
+            out["roofline"]["contract"] = {
+                "flops_per_agent_sample_forward": 18.10e6, "flops_per_update": contract_flops,
+                "tflops_over_the_timed_update": contract_flops / (elapsed / args.steps) / 1e12,
+                "executed_share": (flops / contract_flops) if contract_flops > 0 else None,
+                "note": "what the per-agent evaluation of the reference would have to execute for the same update, over the WHOLE timed "
+                        "step (helpers and env step included); the shared-trunk / slot / patch / background evaluation computes the same "
+                        "function with executed_share of those FLOPs -- this is a statement about the algorithm, not about the matrix pipe"}
             # what the support masks leave of the dense1 patch GEMMs: executed FLOPs against the plain 5x5 patch (2 * samples * 1600 * 512
             # per launch of a chunk of min(E * 10, 81 920) samples)
             chunk_samples = min(E * 10, 81920)
