@@ -406,54 +406,100 @@ __global__ __launch_bounds__(256) void conv1_sparse_kernel(const uint8_t *__rest
 }
 
 // Shared-trunk form of the same layer (net_shared.inc): ONE pre-activation image per env, written straight from registers.
-// A work item is (output pixel, 8 of the 32 channels): 1 600 items per env over 256 lanes (6.25 rounds instead of the 1.56 of a
-// lane per pixel), 8 accumulators per lane, and no 51 KB staging tile in LDS -- only the two 7 KB count grids, so ten workgroups
-// share a CU instead of two.  Same sums in the same order as conv1_sparse_kernel (bit-identical output).
+// Only the pixels whose 8x8 window holds a bin ("touched": ~40 of 400) do arithmetic, the others are b1.  The touched pixels are
+// listed in LDS (400-bit mask from the bins' four covers, compacted in pixel order) and a pixel gets HALF A WAVE, one output
+// channel per lane: a step of the window walk -- one non-zero (row, channel, column) of the count grids -- then costs a dozen
+// instructions for 2 pixels x 32 channels.  (Until round 3 a lane owned 8 channels of one of 16 pixels of its wave: the wave walked
+// the union of its pixels' non-zero taps with 4 of 64 lanes busy per step, ~110 of the kernel's 152 us per 8 192-env chunk; and
+// the count / 80 division sat on that path too -- now tabulated.)  Same sums in the same order as conv1_sparse_kernel
+// (bit-identical output).  nmask (list form of the trunk): the 2 x 2 pixel blocks anybody reads; the rest is not written.
 __global__ __launch_bounds__(256) void conv1_sparse_shared_kernel(const uint8_t *__restrict__ lbins, const uint8_t *__restrict__ abins,
                                                                   const float *__restrict__ w1, const float *__restrict__ b1, int G,
                                                                   float *__restrict__ sraw, const unsigned *__restrict__ nmask) {
     __shared__ unsigned int cnt[2][7056 / 4 + 4];   // 84x84 byte counters per channel, packed 4 per word
-    __shared__ unsigned need[4];                    // 2 x 2 pixel blocks anybody reads (trunk_mark_kernel); nmask == nullptr: all
+    __shared__ unsigned need[4], pm[13];            // blocks anybody reads (nmask == nullptr: all); touched pixels
+    __shared__ float vtab[2][96];                   // count / 80, count / 10 as the reference forms them (float64 division rounded to float32, state_processors.py:33)
+    __shared__ unsigned short plist[400];
+    __shared__ unsigned short evl[8][128];          // per half wave: the non-zero taps of its pixel, in order
+    __shared__ int ntouched;
+    // the two count channels' kernels [tap][c][co]: with the weights in global memory every step of the walk below was a dependent
+    // cache round trip
+    __shared__ __attribute__((aligned(16))) float wl[64 * 2 * 32];
     const int env = blockIdx.x, tid = threadIdx.x;
+    for (int i = tid; i < 64 * 2 * 8; i += 256) {
+        const int t = i >> 4, c = (i >> 3) & 1, j = i & 7;
+        reinterpret_cast<float4 *>(wl)[i] = *reinterpret_cast<const float4 *>(w1 + (t * 3 + c) * 32 + j * 4);
+    }
     if (tid < 4) need[tid] = nmask ? nmask[(size_t)env * 4 + tid] : 0xFFFFFFFFu;
+    if (tid >= 32 && tid < 45) pm[tid - 32] = 0;
+    if (tid >= 64 && tid < 64 + 81) vtab[0][tid - 64] = (float)((double)(tid - 64) / 80.0);
+    if (tid >= 160 && tid < 160 + 11) vtab[1][tid - 160] = (float)((double)(tid - 160) / 10.0);
     for (int i = tid; i < 2 * (7056 / 4 + 4); i += 256) (&cnt[0][0])[i] = 0;
     __syncthreads();
-    if (tid < 80) {
-        int bx = lbins[((size_t)env * 80 + tid) * 2], by = lbins[((size_t)env * 80 + tid) * 2 + 1];
-        if (bx != 255) { int idx = bx * G + by; atomicAdd(&cnt[0][idx >> 2], 1u << (8 * (idx & 3))); }
-    } else if (tid < 90) {
-        int a = tid - 80;
-        int bx = abins[((size_t)env * 10 + a) * 2], by = abins[((size_t)env * 10 + a) * 2 + 1];
-        if (bx != 255) { int idx = bx * G + by; atomicAdd(&cnt[1][idx >> 2], 1u << (8 * (idx & 3))); }
-    }
-    __syncthreads();
-    float4 *out = reinterpret_cast<float4 *>(sraw + (size_t)env * 12800);
-    for (int item = tid; item < 1600; item += 256) {
-        const int pix = item >> 2, c0 = (item & 3) * 8;
-        const int oy = pix / 20, ox = pix - oy * 20, blk = (oy >> 1) * 10 + (ox >> 1);
-        if (!((need[blk >> 5] >> (blk & 31)) & 1u)) continue;
-        float acc[8];
+    if (tid < 90) {
+        const uint8_t *b = tid < 80 ? lbins + ((size_t)env * 80 + tid) * 2 : abins + ((size_t)env * 10 + (tid - 80)) * 2;
+        const int bx = b[0], by = b[1];
+        if (bx != 255) {
+            const int idx = bx * G + by;
+            atomicAdd(&cnt[tid < 80 ? 0 : 1][idx >> 2], 1u << (8 * (idx & 3)));
 #pragma unroll
-        for (int co = 0; co < 8; ++co) acc[co] = b1[c0 + co];
-        for (int ky = 0; ky < 8; ++ky) {
-            const int rowbase = (4 * oy + ky) * G + 4 * ox;   // multiple of 4: G = 84
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                unsigned int w0 = cnt[c][rowbase >> 2], w1_ = cnt[c][(rowbase >> 2) + 1];
-                if ((w0 | w1_) == 0) continue;
-#pragma unroll
-                for (int kx = 0; kx < 8; ++kx) {
-                    unsigned int k = ((kx < 4 ? w0 : w1_) >> (8 * (kx & 3))) & 255u;
-                    if (k == 0) continue;
-                    float val = (float)((double)k / (c == 0 ? 80.0 : 10.0));      // state_processors.py:33
-                    const float *wp = w1 + ((ky * 8 + kx) * 3 + c) * 32 + c0;
-#pragma unroll
-                    for (int co = 0; co < 8; ++co) acc[co] += val * wp[co];
-                }
+            for (int c = 0; c < 4; ++c) {      // the four conv1 outputs whose window holds the bin
+                const int oy = (bx >> 2) - (c >> 1), ox = (by >> 2) - (c & 1);
+                if (oy >= 0 && oy < 20 && ox >= 0 && ox < 20) atomicOr(&pm[(oy * 20 + ox) >> 5], 1u << ((oy * 20 + ox) & 31));
             }
         }
-        out[item * 2] = make_float4(acc[0], acc[1], acc[2], acc[3]);
-        out[item * 2 + 1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    }
+    __syncthreads();
+    for (int p = tid; p < 400; p += 256)
+        if ((pm[p >> 5] >> (p & 31)) & 1u) {
+            int before = __popc(pm[p >> 5] & ((1u << (p & 31)) - 1u));
+            for (int w = 0; w < (p >> 5); ++w) before += __popc(pm[w]);
+            plist[before] = (unsigned short)p;
+        }
+    if (tid == 0) {
+        int n = 0;
+        for (int w = 0; w < 13; ++w) n += __popc(pm[w]);
+        ntouched = n;
+    }
+    // the untouched pixels somebody reads: b1
+    float4 *out = reinterpret_cast<float4 *>(sraw + (size_t)env * 12800);
+    for (int item = tid; item < 3200; item += 256) {
+        const int pix = item >> 3, oy = pix / 20, ox = pix - oy * 20, blk = (oy >> 1) * 10 + (ox >> 1);
+        if (!((need[blk >> 5] >> (blk & 31)) & 1u) || ((pm[pix >> 5] >> (pix & 31)) & 1u)) continue;
+        out[item] = *reinterpret_cast<const float4 *>(b1 + (item & 7) * 4);
+    }
+    __syncthreads();
+    // A touched pixel gets half a wave.  Its 8 x 8 x 2 window is 32 count words: lane l reads word (ky = l >> 2, c = (l >> 1) & 1,
+    // half = l & 1), the non-zero bytes of all lanes are listed in (ky, c, kx) order -- the order conv1_sparse_kernel adds them in --
+    // through a shuffle scan of the per-lane counts, and the 32 lanes then walk the list together, one output channel each.
+    const int co = tid & 31, hw = tid >> 5, nt = ntouched;
+    unsigned short *ev = evl[hw];
+    for (int t = hw; t < ((nt + 7) & ~7); t += 8) {      // whole waves run every round (the shuffles)
+        const bool live = t < nt;
+        const int pix = live ? plist[t] : 0, oy = pix / 20, ox = pix - oy * 20;
+        const int ky = co >> 2, c = (co >> 1) & 1, half = co & 1;
+        const unsigned int w = live ? cnt[c][(((4 * oy + ky) * G + 4 * ox) >> 2) + half] : 0u;      // rowbase is a multiple of 4: G = 84
+        const int n = (w & 0xFFu ? 1 : 0) + (w & 0xFF00u ? 1 : 0) + (w & 0xFF0000u ? 1 : 0) + (w >> 24 ? 1 : 0);
+        int incl = n;
+#pragma unroll
+        for (int d = 1; d < 32; d <<= 1) {
+            const int o = __shfl_up(incl, d, 32);
+            if (co >= d) incl += o;
+        }
+        const int total = __shfl(incl, 31, 32);
+        int at = incl - n;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned int k = (w >> (8 * j)) & 255u;
+            if (k) ev[at++] = (unsigned short)((((ky * 8 + half * 4 + j) * 2 + c) << 7) | k);      // tap-and-channel row of wl, count
+        }
+        // (a half wave's LDS writes are visible to its own lanes after the wait the compiler places before the reads: same wave)
+        float acc = b1[co];
+        for (int e = 0; e < total; ++e) {
+            const int code = ev[e];
+            acc += vtab[(code >> 7) & 1][code & 127] * wl[(code >> 7) * 32 + co];
+        }
+        if (live) sraw[(size_t)env * 12800 + pix * 32 + co] = acc;
     }
 }
 
