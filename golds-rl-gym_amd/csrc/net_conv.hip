@@ -95,6 +95,8 @@ struct NetLane {
     // the shared trunk's affected conv2 rows (trunk_index, net_shared.inc): 81-bit mask per env, row list + live count
     unsigned *tamask, *tbmask, *tcmask, *tnmask;      // (tnmask: blocks of sraw anybody reads) + 100-bit mask of touched 2x2 conv1 pixel blocks, 49-bit mask of affected conv3 outputs
     int *trowlist, *tblklist, *tc3list, *trows_n, *twgcnt, *twgoff;      // their lists, live counts [conv2 rows, blocks, conv3 rows], scan scratch
+    unsigned *tumask;          // union of the chunk's conv3 masks (2 words)
+    float *tubias;             // dense1's per-env bias under that union (trunk_ubias_kernel)
     float *tslab, *tsums;      // tslab: per-workgroup sums of dz2 over unaffected rows; tsums: [dz2 total 64 | unaffected 64]
     unsigned *stmask, *szmask;      // ... and per row range of the slot weight gradient (slot_wgrad_launch)
     int *sbase, *rowagent, *sblk;      // compact slot rows (net_shared.inc): prefix of per-sample slot counts, row -> sample, scan scratch
@@ -136,7 +138,7 @@ struct grl_net : NetLane {
     double pfrac[3];           // executed share of the dense1 patch GEMMs' FLOPs in the last sorted chunk (profiling pass only; else 1)
     // the background's way through the trunk (trunk_background, net_shared.inc; per parameter version): the all-b1 image, [z2 | a2] of
     // its conv2 row, a2 at all 81 pixels, [z3 | a3] of its conv3 row, the one-row list of those passes
-    float *tbgimg, *tbgz, *tbgimg3, *tbgz3;
+    float *tbgimg, *tbgz, *tbgimg3, *tbgz3, *tybg;      // tybg[49][512]: a background pixel's contribution to dense1 (trunk_ybg_kernel)
     int *tbglist;
     int trunk_skip;            // 1: conv2's forward / weight gradient / transposed convolution run over the rows the env's bins reach (GRL_TRUNK_SKIP=off: all rows)
     int patch_skip;            // 1: the dense1 patch GEMMs skip what the support masks say is zero (GRL_PATCH_SKIP=off: the plain 5x5 patch)
@@ -773,6 +775,8 @@ static int alloc_lane_forward(grl_net *n) {
     if (rc == GRL_OK) rc = nalloc(n, &n->trows_n, 4);
     if (rc == GRL_OK) rc = nalloc(n, &n->twgcnt, ((c / 10 + TRUNK_ENVS - 1) / TRUNK_ENVS + 1) * 3);
     if (rc == GRL_OK) rc = nalloc(n, &n->twgoff, ((c / 10 + TRUNK_ENVS - 1) / TRUNK_ENVS + 1) * 3);
+    if (rc == GRL_OK) rc = nalloc(n, &n->tumask, 4);
+    if (rc == GRL_OK) rc = nalloc(n, &n->tubias, 512);
     if (rc == GRL_OK) rc = nalloc(n, &n->tslab, 2 * 2048 * 64);
     if (rc == GRL_OK) rc = nalloc(n, &n->tsums, 256);
     A(&n->carow, c * 128);
@@ -879,7 +883,7 @@ int grl_net_create(grl_handle *h, const grl_net_config *cfg, grl_net **out) {
     auto A = [&](float **p, size_t cnt) { if (rc == GRL_OK) rc = nalloc(n, p, cnt); };
     A(&n->params, n->ho.total); A(&n->paramsT, n->ho.total); A(&n->adam_m, n->ho.total); A(&n->adam_v, n->ho.total);
     A(&n->w3f, 576 * 64); A(&n->stats, 16); A(&n->w2corr, 4 * 576 * 128);
-    A(&n->tbgimg, 12800); A(&n->tbgz, 128); A(&n->tbgimg3, 5184); A(&n->tbgz3, 128);
+    A(&n->tbgimg, 12800); A(&n->tbgz, 128); A(&n->tbgimg3, 5184); A(&n->tbgz3, 128); A(&n->tybg, 49 * 512);
     if (rc == GRL_OK) rc = nalloc(n, &n->tbglist, 4);
     int nlanes = (cfg->reserved & GRL_NET_F_SINGLE_STREAM) ? 1 : 4;      // measured at 32 768 envs: 1.41 / 1.22 / 1.16 / 1.13 / 1.14 s per update with 1 / 2 / 3 / 4 / 8
     if (const char *env = getenv("GRL_NET_LANES")) { int v = atoi(env); if (v >= 1 && v <= GRL_MAX_LANES) nlanes = v; }      // tuning knob

@@ -291,6 +291,24 @@ struct DenseRows {   // plain row-major [rows][ld], reduction length k
     __device__ __forceinline__ void mrange(int z, int mc, int &mbeg, int &mend) const { mbeg = z * mc; mend = min(rows, mbeg + mc); }
 };
 
+// dense1's per-env GEMMs under the chunk's union mask U (net_shared.inc, trunk_index: bit p = conv3 output p is affected in SOME env
+// of the chunk; everywhere else a3sh is the background row in every env).  The 3 136 inputs are 49 pixels x 64 channels, so a
+// 64-wide tile of that axis is one pixel: the forward skips the K-tiles of the pixels outside U (their constant contribution rides
+// in the bias), the data gradient does not compute their column tiles (only their sum over the envs is needed: closed form), the
+// weight gradient writes no slab tile for their rows (rank-1 closed form).
+struct DenseRowsKU : DenseRows {
+    const unsigned *u;
+    __device__ __forceinline__ bool tile_ok(int, int k0) const { return (u[k0 >> 11] >> ((k0 >> 6) & 31)) & 1u; }
+};
+struct DenseRowsNU : DenseRows {
+    const unsigned *u;
+    __device__ __forceinline__ bool n_ok(int, int n0) const { return (u[n0 >> 11] >> ((n0 >> 6) & 31)) & 1u; }
+};
+struct DenseRowsIU : DenseRows {
+    const unsigned *u;
+    __device__ __forceinline__ bool i_ok(int, int i0) const { return (u[i0 >> 11] >> ((i0 >> 6) & 31)) & 1u; }
+};
+
 // `groups` row-major [npad][ld] operands stacked along M (rows = groups * npad, the first `nlive` rows of each live), every one
 // against its own `bnstep`-row block of Bt -- the four conv1-pixel parity classes of the conv2 corrections in ONE launch
 // instead of four launch-latency-bound ones.  gemm_tn: grid z = group * cpc + c reduces rows [c*mc, (c+1)*mc) of its group.

@@ -442,7 +442,10 @@ def test_gradient_paths_agree_at_tile_multiple_sizes():
             # differs: tools/cmp_expand2.py); on this seed that moves a few more near-zero ReLU inputs of conv3 / dense1 across
             # zero -- 1.1e-4 in dense1 (3 elements), 1.45e-3 in conv1_w (tools/diag_paths.py prints both kernels side by side).
             # The statistic is "which handful of inputs sits within round-off of zero", so the bound is loose by nature.
-            tol = 3e-3 if name == "conv1_w" else (1e-3 if name.startswith(("conv", "dense1")) else 5e-6)
+            # Round 3: dense1's per-env part adds the background pixels' share as one term (net_shared.inc, union mask); d1 moves by
+            # 3e-8 (no sign differs), and on this seed ONE ReLU input of v1 crosses zero: v1_b differs in one element by 7.8e-5 of the
+            # block's largest, and that sample's rank-1 share reaches dense2 and below at 1e-5 (tools/diag_union.py lists the blocks).
+            tol = 3e-3 if name == "conv1_w" else (1e-3 if name.startswith(("conv", "dense1")) else 2e-4 if name.startswith(("dense2", "v1")) else 5e-6)
             assert err < tol, (name, err)
     for s in stats[:4]:
         np.testing.assert_allclose(s["loss"], stats[4]["loss"], rtol=1e-5)
@@ -590,8 +593,9 @@ def test_trunk_row_lists_change_nothing_but_the_work(monkeypatch):
     """The env's shared trunk is mostly background: conv1 pixels no bin touches hold b1, conv2 outputs whose window sees none of the
     touched pixels are one constant vector.  With GRL_TRUNK_SKIP (default) conv2's forward runs over the affected rows plus one
     background row, its weight gradient over the affected rows plus a rank-1 term, its transposed convolution over the touched
-    pixel blocks, and conv1's bias gradient takes the background's part in closed form (net_shared.inc).  Forward: the same bits.
-    Gradient: the same sums in another association -- 2e-6 of each block's largest entry.  Non-zero biases (the background terms
+    pixel blocks, conv1's bias gradient takes the background's part in closed form, and dense1's per-env GEMMs skip the pixels no env
+    of the chunk reaches (net_shared.inc).  The same sums in another association: heads within 2e-6, gradients within 2e-6 of each
+    block's largest entry.  Non-zero biases (the background terms
     vanish with b1 = 0), envs from crowded to empty (every locust outside the box), ragged chunks."""
     from goldsrl import _ffi, _ffi_net
     E = 90
@@ -628,8 +632,8 @@ def test_trunk_row_lists_change_nothing_but_the_work(monkeypatch):
         assert np.array_equal(g1, net.get_grads()), "gradient not reproducible (%s)" % mode
         res[mode] = (out, stats, g1)
         net.close()
-    for k in ("mu", "sigma", "vs"):
-        assert np.array_equal(res["on"][0][k], res["off"][0][k]), k
+    for k in ("mu", "sigma", "vs"):      # conv1-conv3: the same bits; dense1's per-env part adds the background pixels' share as one term
+        np.testing.assert_allclose(res["on"][0][k], res["off"][0][k], rtol=2e-6, atol=1e-7, err_msg=k)
     np.testing.assert_allclose(list(res["on"][1].values()), list(res["off"][1].values()), rtol=1e-6)
     gon, goff = NN.unflatten_params(res["on"][2].astype(np.float64)), NN.unflatten_params(res["off"][2].astype(np.float64))
     for k in gon:

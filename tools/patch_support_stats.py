@@ -56,6 +56,7 @@ print("live (slot, tap) pairs: %.1f %% of 9 per slot" % (100.0 * live / tot))
 lbn = eng.read("locust_bins").reshape(E, 80, 2).astype(int)
 abn = eng.read("agent_bins").reshape(E, 10, 2).astype(int)
 t1 = t2 = t3 = inbox = ubins = 0
+o3all, o2all = [], []
 for e in range(0, E, 8):
     pts = np.concatenate([lbn[e], abn[e]])
     pts = pts[pts[:, 0] != 255]
@@ -79,7 +80,17 @@ for e in range(0, E, 8):
     t3 += o3.sum()
     inbox += len(pts)
     ubins += len({(h, w) for h, w in pts})
+    o3all.append(o3.copy()); o2all.append(o2.copy())
 ne = len(range(0, E, 8))
 print("points inside the box: %.1f of 90 per env, distinct bins %.1f; conv3 outputs that see an affected conv2 output: %.1f of 49"
       % (inbox / ne, ubins / ne, t3 / ne))
 print("shared trunk: conv1 outputs touched by any bin: %.1f of 400 per env; conv2 outputs that see a touched input: %.1f of 81" % (t1 / ne, t2 / ne))
+
+# do the envs' affected sets coincide?  union over groups of 128 envs (what a 128-row GEMM tile would have to cover)
+o3a, o2a = np.array(o3all), np.array(o2all)
+for g in (16, 128, len(o3a)):
+    u3 = [o3a[i:i + g].any(axis=0).sum() for i in range(0, len(o3a) - g + 1, g)]
+    u2 = [o2a[i:i + g].any(axis=0).sum() for i in range(0, len(o2a) - g + 1, g)]
+    print("union of the affected sets over %d envs: conv3 outputs %.1f of 49, conv2 outputs %.1f of 81" % (g, np.mean(u3), np.mean(u2)))
+print("how often each conv3 output is affected (7x7, per cent of envs):")
+print(np.round(100 * o3a.mean(axis=0)).astype(int))
