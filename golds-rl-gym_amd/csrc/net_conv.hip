@@ -97,6 +97,7 @@ struct NetLane {
     int *trowlist, *tblklist, *tc3list, *trows_n, *twgcnt, *twgoff;      // their lists, live counts [conv2 rows, blocks, conv3 rows], scan scratch
     unsigned *tumask;          // union of the chunk's conv3 masks (2 words)
     float *tubias;             // dense1's per-env bias under that union (trunk_ubias_kernel)
+    float *tug, *tuspix;       // gradient side: G = column sums of gd1sh (512), per-pixel closed-form sums (49 x 64)
     float *tslab, *tsums;      // tslab: per-workgroup sums of dz2 over unaffected rows; tsums: [dz2 total 64 | unaffected 64]
     unsigned *stmask, *szmask;      // ... and per row range of the slot weight gradient (slot_wgrad_launch)
     int *sbase, *rowagent, *sblk;      // compact slot rows (net_shared.inc): prefix of per-sample slot counts, row -> sample, scan scratch
@@ -777,6 +778,8 @@ static int alloc_lane_forward(grl_net *n) {
     if (rc == GRL_OK) rc = nalloc(n, &n->twgoff, ((c / 10 + TRUNK_ENVS - 1) / TRUNK_ENVS + 1) * 3);
     if (rc == GRL_OK) rc = nalloc(n, &n->tumask, 4);
     if (rc == GRL_OK) rc = nalloc(n, &n->tubias, 512);
+    if (rc == GRL_OK) rc = nalloc(n, &n->tug, 512);
+    if (rc == GRL_OK) rc = nalloc(n, &n->tuspix, 49 * 64);
     if (rc == GRL_OK) rc = nalloc(n, &n->tslab, 2 * 2048 * 64);
     if (rc == GRL_OK) rc = nalloc(n, &n->tsums, 256);
     A(&n->carow, c * 128);

@@ -589,7 +589,8 @@ def test_patch_support_masks_change_nothing_but_the_work(monkeypatch):
     eng.close()
 
 
-def test_trunk_row_lists_change_nothing_but_the_work(monkeypatch):
+@pytest.mark.parametrize("layout", ["mixed", "strip"])
+def test_trunk_row_lists_change_nothing_but_the_work(monkeypatch, layout):
     """The env's shared trunk is mostly background: conv1 pixels no bin touches hold b1, conv2 outputs whose window sees none of the
     touched pixels are one constant vector.  With GRL_TRUNK_SKIP (default) conv2's forward runs over the affected rows plus one
     background row, its weight gradient over the affected rows plus a rank-1 term, its transposed convolution over the touched
@@ -612,6 +613,9 @@ def test_trunk_row_lists_change_nothing_but_the_work(monkeypatch):
             pos[e, :2] = 255
         if e % 5 == 0:        # agents on the rim
             pos[e, 2:6, 0] = rng.choice([0, 1, 82, 83], size=4)
+    if layout == "strip":      # the bench workload's geometry: every point of every env in one strip of the grid, so that the chunk's
+        lb[lb[:, :, 0] != 255, 1] %= 22      # UNION of affected conv3 outputs is a proper subset too (dense1's per-env GEMMs skip the rest)
+        pos[pos[:, :, 0] != 255, 1] %= 22
     ab = pos.copy()
     act, adv, y = _train_inputs(E, seed=16)
     flat = _ffi_net.glorot_uniform_flat(seed=17).astype(np.float64)
