@@ -1433,30 +1433,28 @@ __global__ void slab_reduce_groups_kernel(const float *__restrict__ slab, int ch
 }
 
 // Same for a short row (n up to a few thousand) and many chunks, where one lane per element would walk the chunks
-// serially: 16 elements per workgroup, 16 lanes per element each summing every 16th chunk, combined in fixed order.
+// serially: 4 elements per workgroup, a wave per element -- lane p sums the chunks p, p + 64, ... in four interleaved partial sums,
+// the 64 lanes are folded in a fixed shuffle tree.  (Until round 3: 16 elements per workgroup and 16 lanes per element -- 4 workgroups
+// for a 64-wide bias gradient over 1 500 partial rows, 11 us of mostly waiting; ~20 such launches per chunk of the gradient step.)
+constexpr int kNarrowCols = 4;
 __global__ __launch_bounds__(256) void slab_reduce_narrow_kernel(const float *__restrict__ slab, int chunks, int n, float *__restrict__ dst,
                                                                  int accumulate) {
-    __shared__ float red[256];
-    const int col = threadIdx.x & 15, part = threadIdx.x >> 4;
-    const int i = blockIdx.x * 16 + col;
+    const int lane = threadIdx.x & 63, i = blockIdx.x * kNarrowCols + (threadIdx.x >> 6);
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (i < n) {
-        int c = part;
-        for (; c + 48 < chunks; c += 64) {
+        int c = lane;
+        for (; c + 192 < chunks; c += 256) {
             s0 += slab[(long)c * n + i];
-            s1 += slab[(long)(c + 16) * n + i];
-            s2 += slab[(long)(c + 32) * n + i];
-            s3 += slab[(long)(c + 48) * n + i];
+            s1 += slab[(long)(c + 64) * n + i];
+            s2 += slab[(long)(c + 128) * n + i];
+            s3 += slab[(long)(c + 192) * n + i];
         }
-        for (; c < chunks; c += 16) s0 += slab[(long)c * n + i];
+        for (; c < chunks; c += 64) s0 += slab[(long)c * n + i];
     }
-    red[threadIdx.x] = (s0 + s1) + (s2 + s3);
-    __syncthreads();
-    if (part == 0 && i < n) {
-        float s = red[col];
-        for (int r = 1; r < 16; ++r) s += red[r * 16 + col];
-        dst[i] = accumulate ? dst[i] + s : s;
-    }
+    float s = (s0 + s1) + (s2 + s3);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);      // every lane ends with the same value: a fixed tree
+    if (lane == 0 && i < n) dst[i] = accumulate ? dst[i] + s : s;
 }
 
 // column sums of dY[M][J] over row chunks -> slab[chunk][J]   (bias gradients)
