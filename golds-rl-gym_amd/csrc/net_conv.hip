@@ -647,7 +647,7 @@ static void bind_activations(grl_net *net, long slot) {
 // reuse_tail: a3..v2 of this chunk are already resident (bind_activations); only the cheap per-env trunk, the
 // per-agent a2 and the heads are re-evaluated
 static int forward_chunk(grl_net *net, const uint8_t *lb, const uint8_t *ab, const uint8_t *pos, int nenv, float *mu,
-                         float *sigma, float *vs, bool reuse_tail = false) {
+                         float *sigma, float *vs, bool reuse_tail = false, bool skip_heads = false) {
     hipStream_t st = net->h->stream;
     const float *P = net->params, *PT = net->paramsT;
     const int n = nenv * 10;
@@ -696,6 +696,7 @@ static int forward_chunk(grl_net *net, const uint8_t *lb, const uint8_t *ab, con
     dense(net->d2, 256, PT + net->ho.v1w, P + net->ho.v1b, 512, net->v1);
     dense(net->v1, 512, PT + net->ho.v2w, P + net->ho.v2b, 256, net->v2);
     }
+    if (!skip_heads)      // (the gradient step over a resident rollout has the heads' outputs of every step already)
     GRL_HEADS_DISPATCH(net->ho.A, hipLaunchKernelGGL(heads_forward_kernel<kA>, dim3((n + 4 * kHeadRows - 1) / (4 * kHeadRows)), dim3(256), 0, st, net->p1, net->v2, P, net->ho, n,
                                                       net->cfg.scale, mu, sigma, vs));
     NET_HIP(net, hipGetLastError());
