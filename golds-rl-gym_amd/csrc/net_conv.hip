@@ -116,6 +116,8 @@ struct NetLane {
     float *ro_mu;              // chunk-sized scratch of the gradient step (cmu csigma cvs dzh cact cadv cy)
     float *ws_a3, *ws_d1, *ws_d2, *ws_p1, *ws_v1, *ws_v2, *ws_a3sh, *ws_d3;   // chunk workspace (the default binding)
     unsigned long long *ws_m3;
+    // sign bits of d2 / v1 (4 + 8 words of 64 column bits per sample: EpiBiasActBits, net_gemm.h), bound like the activations
+    unsigned long long *mb_d2, *mb_v1, *ws_mb;
     float *ws_sraw, *ws_a2sh, *ws_d2s;
     unsigned long long *ws_m2s;
     signed char *ws_ulist;
@@ -607,7 +609,7 @@ __global__ void sample_actions_kernel(const float *__restrict__ mu, const float 
 // floats kept per chunk slot: per-agent-trunk mode a3 + dense stack; shared mode a3sh (per env) + d3 + patch mask + dense stack,
 // and at level 2 also what the gradient step reads of the per-env trunk: sraw, a2sh (per env), d2s, slot mask, ulist (per slot)
 static size_t keep_floats_per_slot(const grl_net *net, int level) {
-    const size_t c = net->chunk, dense = 512 + 256 + 512 + 512 + 256;
+    const size_t c = net->chunk, dense = 512 + 256 + 512 + 512 + 256 + 32;      // + the sign bits of d2 and v1 (12 words per sample, padded to 16)
     if (!net->shared_trunk) return c * (3136 + dense);
     size_t f = (c / 10) * 3136 + c * (1600 + 50 + dense);      // m3: 25 x 8 bytes per sample
     if (level >= 2) f += (c / 10) * (12800 + 5184) + c * (576 + 18) + ((c * 9 + 3) / 4 + 3) / 4 * 4;      // stays a multiple of 16 bytes
@@ -619,6 +621,7 @@ static size_t keep_floats_per_slot(const grl_net *net, int level) {
 static void bind_activations(grl_net *net, long slot) {
     net->a3 = net->ws_a3; net->d1 = net->ws_d1; net->d2 = net->ws_d2; net->p1 = net->ws_p1; net->v1 = net->ws_v1; net->v2 = net->ws_v2;
     net->a3sh = net->ws_a3sh; net->d3 = net->ws_d3; net->m3 = net->ws_m3;
+    net->mb_d2 = net->ws_mb; net->mb_v1 = net->ws_mb + (size_t)net->chunk * 4;
     net->sraw = net->ws_sraw; net->a2sh = net->ws_a2sh; net->d2s = net->ws_d2s; net->m2s = net->ws_m2s; net->ulist = net->ws_ulist;
     if (slot < 0 || !net->keep) return;
     const size_t c = net->chunk;
@@ -635,6 +638,7 @@ static void bind_activations(grl_net *net, long slot) {
     net->p1 = b; b += c * 512;
     net->v1 = b; b += c * 512;
     net->v2 = b; b += c * 256;
+    net->mb_d2 = reinterpret_cast<unsigned long long *>(b); net->mb_v1 = net->mb_d2 + c * 4; b += c * 32;      // 12 words per sample + 8 words of padding: the slot stays a multiple of 128 bytes
     if (net->shared_trunk && net->keep_level >= 2) {
         net->sraw = b; b += (c / 10) * 12800;
         net->a2sh = b; b += (c / 10) * 5184;
@@ -684,17 +688,23 @@ static int forward_chunk(grl_net *net, const uint8_t *lb, const uint8_t *ab, con
         launch_rowk<256, 64, kW256M, kW256N, GatherConv3, EpiBiasAct>(net, dim3(1, (n * 49 + 255) / 256), st, g, PT + ConvOffsets::c3w, 576, 64, e);
     }
     net->prof_tag_cur = net->shared_trunk ? PT_DENSE_FWD : PT_PER_AGENT;
-    auto dense = [&](const float *in, int K, const float *w, const float *b, int N, float *out) {
+    // bits != nullptr: the epilogue also keeps the sign bits of what it stores (the data gradient above reads them instead of the tensor)
+    auto dense = [&](const float *in, int K, const float *w, const float *b, int N, float *out, unsigned long long *bits) {
         DenseRows g{in, n, K, K};
-        EpiBiasAct e{out, N, b, ACT_RELU};
         GemmTimer t(net, 2.0 * n * K * N);
-        launch_rowk<128, 128, kW128M, kW128N, DenseRows, EpiBiasAct>(net, dim3(N / 128, (n + 127) / 128), st, g, w, K, N, e);
+        if (bits) {
+            EpiBiasActBits e{out, N, b, bits, N >> 6};
+            launch_rowk<128, 128, kW128M, kW128N, DenseRows, EpiBiasActBits>(net, dim3(N / 128, (n + 127) / 128), st, g, w, K, N, e);
+        } else {
+            EpiBiasAct e{out, N, b, ACT_RELU};
+            launch_rowk<128, 128, kW128M, kW128N, DenseRows, EpiBiasAct>(net, dim3(N / 128, (n + 127) / 128), st, g, w, K, N, e);
+        }
     };
-    if (!net->shared_trunk) dense(net->a3, 3136, PT + ConvOffsets::d1w, P + ConvOffsets::d1b, 512, net->d1);
-    dense(net->d1, 512, PT + ConvOffsets::d2w, P + ConvOffsets::d2b, 256, net->d2);
-    dense(net->d2, 256, PT + ConvOffsets::p1w, P + ConvOffsets::p1b, 512, net->p1);
-    dense(net->d2, 256, PT + net->ho.v1w, P + net->ho.v1b, 512, net->v1);
-    dense(net->v1, 512, PT + net->ho.v2w, P + net->ho.v2b, 256, net->v2);
+    if (!net->shared_trunk) dense(net->a3, 3136, PT + ConvOffsets::d1w, P + ConvOffsets::d1b, 512, net->d1, nullptr);
+    dense(net->d1, 512, PT + ConvOffsets::d2w, P + ConvOffsets::d2b, 256, net->d2, net->mb_d2);
+    dense(net->d2, 256, PT + ConvOffsets::p1w, P + ConvOffsets::p1b, 512, net->p1, nullptr);
+    dense(net->d2, 256, PT + net->ho.v1w, P + net->ho.v1b, 512, net->v1, net->mb_v1);
+    dense(net->v1, 512, PT + net->ho.v2w, P + net->ho.v2b, 256, net->v2, nullptr);
     }
     if (!skip_heads)      // (the gradient step over a resident rollout has the heads' outputs of every step already)
     GRL_HEADS_DISPATCH(net->ho.A, hipLaunchKernelGGL(heads_forward_kernel<kA>, dim3((n + 4 * kHeadRows - 1) / (4 * kHeadRows)), dim3(256), 0, st, net->p1, net->v2, P, net->ho, n,
@@ -736,6 +746,8 @@ static int alloc_lane_forward(grl_net *n) {
     A(&n->a3sh, (c / 10) * 3136); A(&n->d3, c * 1600); if (rc == GRL_OK) rc = nalloc(n, &n->m3, c * 25); A(&n->ysh, (c / 10) * 512);
     n->ws_a3 = n->a3; n->ws_d1 = n->d1; n->ws_d2 = n->d2; n->ws_p1 = n->p1; n->ws_v1 = n->v1; n->ws_v2 = n->v2;
     n->ws_a3sh = n->a3sh; n->ws_d3 = n->d3; n->ws_m3 = n->m3;
+    if (rc == GRL_OK) rc = nalloc(n, &n->ws_mb, c * 12);
+    n->mb_d2 = n->ws_mb; n->mb_v1 = n->ws_mb + c * 4;
     n->ws_sraw = n->sraw; n->ws_a2sh = n->a2sh; n->ws_d2s = n->d2s; n->ws_m2s = n->m2s; n->ws_ulist = n->ulist;
     if (rc == GRL_OK) rc = nalloc(n, &n->perm, (size_t)n->ptiles * 256);
     if (rc == GRL_OK) rc = nalloc(n, &n->goffp, 32);

@@ -49,6 +49,11 @@ struct epi_row_bits<E, std::void_t<decltype(E::kRowBits)>> : std::bool_constant<
 
 // an epilogue whose elem_aux is ADDED to the accumulator (bias, per-env part, shared pre-activation) says so: the range guard
 // checks what is stored, not the bare product (kAddAux)
+// kRowAuxN: row_aux_n(r, colbase) instead of row_aux(r), without the sign-bit output of kRowBits
+template <class E, class = void>
+struct epi_row_auxn : std::false_type {};
+template <class E>
+struct epi_row_auxn<E, std::void_t<decltype(E::kRowAuxN)>> : std::bool_constant<E::kRowAuxN> {};
 template <class E, class = void>
 struct epi_add_aux : std::false_type {};
 template <class E>
@@ -576,6 +581,26 @@ struct EpiBiasAct {
     }
 };
 
+// EpiBiasAct (ReLU) that also keeps the SIGN of what it stores: one word of 64 column bits per row and 64-column block
+// (bits[r * wpr + (c >> 6)], through the kRowBits ballots).  The data gradient of the layer above needs of this tensor only
+// relu' = (value > 0): 8 bytes per output row and lane instead of 32 floats (EpiGradSumBits) -- 250 MB less per chunk of the
+// gradient step for d2 and v1 (1.5 us more per forward GEMM).  d1 keeps its fp32 mask: its producer's epilogue (EpiPatchFwd, rows
+// scattered through the group sort) paid 9 us for the ballots, more than the data gradient gained.
+struct EpiBiasActBits {
+    static constexpr bool kColSum = false, kAddAux = true;
+    static constexpr bool kRowBits = true;
+    float *C;
+    int ldc;
+    const float *bias;
+    unsigned long long *bits;
+    int wpr;
+    __device__ __forceinline__ int row_aux_n(int, int) const { return 0; }
+    __device__ __forceinline__ float elem_aux(int, int c, int) const { return bias[c]; }
+    __device__ __forceinline__ void store(int r, int c, float v, int, float ea) const { C[(long)r * ldc + c] = fmaxf(v + ea, 0.f); }
+    __device__ __forceinline__ bool bit(float v, float ea) const { return v + ea > 0.f; }
+    __device__ __forceinline__ void store_bits(int r, int colbase, unsigned long long w, int) const { bits[(long)r * wpr + (colbase >> 6)] = w; }
+};
+
 struct EpiBiasDual {
     static constexpr bool kColSum = false, kAddAux = true;   // C[r][c] = v + bias[c] and C2[r][c] = relu(v + bias[c]): pre-activation and activation in one pass
     float *C, *C2;
@@ -682,6 +707,25 @@ struct EpiGradSum {
     float *csum;
     __device__ __forceinline__ int row_aux(int) const { return 0; }
     __device__ __forceinline__ float elem_aux(int r, int c, int) const { return fwd[(long)r * ld + c]; }
+    __device__ __forceinline__ float value(float v, float ea) const { return ea > 0.f ? v : 0.f; }
+    __device__ __forceinline__ void store(int r, int c, float v, int, float ea) const { dX[(long)r * ld + c] = value(v, ea); }
+};
+
+// EpiGradSum with the forward tensor's ReLU mask read from its sign bits (EpiBiasActBits): same values.  One 8-byte load per output
+// row of the lane: a wave covers one 64-column block, the lane its columns l16 + 16 b -- their four bits ride in the row's aux word
+// (a load per ELEMENT, as the fp32 mask needs, made this epilogue 50 % slower than reading the tensor)
+struct EpiGradSumBits {
+    static constexpr bool kColSum = true;
+    static constexpr bool kRowAuxN = true;
+    float *dX;
+    int ld;
+    const unsigned long long *bits;     // [rows][ld / 64]
+    float *csum;
+    __device__ __forceinline__ int row_aux_n(int r, int colbase) const {
+        const unsigned long long w = bits[(long)r * (ld >> 6) + (colbase >> 6)] >> (threadIdx.x & 15);
+        return (int)((w & 1ull) | ((w >> 15) & 2ull) | ((w >> 30) & 4ull) | ((w >> 45) & 8ull));
+    }
+    __device__ __forceinline__ float elem_aux(int, int c, int ra) const { return ((ra >> ((c >> 4) & 3)) & 1) ? 1.f : 0.f; }
     __device__ __forceinline__ float value(float v, float ea) const { return ea > 0.f ? v : 0.f; }
     __device__ __forceinline__ void store(int r, int c, float v, int, float ea) const { dX[(long)r * ld + c] = value(v, ea); }
 };
@@ -1074,7 +1118,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void gemm_rowk(AG ag
     for (int a = 0; a < TM; ++a)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            if constexpr (epi_row_bits<Epi>::value) rax[a][r] = epi.row_aux_n(min(erow + a * 16 + r, M - 1), n0 + wn * WN);
+            if constexpr (epi_row_bits<Epi>::value || epi_row_auxn<Epi>::value) rax[a][r] = epi.row_aux_n(min(erow + a * 16 + r, M - 1), n0 + wn * WN);
             else rax[a][r] = epi.row_aux(min(erow + a * 16 + r, M - 1));
         }
 #pragma unroll
