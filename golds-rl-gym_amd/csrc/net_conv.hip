@@ -73,7 +73,8 @@ struct NetLane {
     // a2_a[u], a2_a[u] - a2sh[u], T3(dz3_a)[u], masked dz2_a[u]; tmpw3: correction GEMM output before the tap flip
     float *a2sh, *d2s, *gsl, *dza, *dz3sh, *tmpw3;
     unsigned long long *m2s;   // ReLU mask of the touched conv2 pixels: one word of 64 channel bits per compact slot row
-    float *at2, *dl2, *tt2, *tmpw2;   // conv2-level corrections as class-major GEMM operands (net_shared.inc)
+    float *dl2, *tt2, *tmpw2;   // conv2-level corrections as class-major GEMM operands (net_shared.inc)
+    int2 *t2desc;               // ... and the gather descriptors of their A rows (T2SlotGather)
     // shared conv3 forward: z3sh = conv3(a2sh) + b3 per env; the per-slot products (a2_a - a2sh)[u] . W3[tap]
     // (n*9 x 576) live in the a2 buffer, which has no other use in shared-trunk mode
     float *z3sh;

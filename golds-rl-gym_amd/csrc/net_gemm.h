@@ -346,6 +346,45 @@ struct DenseRowsGroups {
     }
 };
 
+// The class-major operand of conv2's per-agent corrections WITHOUT its copy in memory (round 3; gather_t2_kernel used to write
+// at2[k][m][(ty, tx, co)] = the agent's masked dz2 row at conv2 output o(ty, tx), 335 MB per chunk, read back twice).  The agent's
+// rows now sit in a canonical 3 x 3 grid dza[m][sy][sx][64] (cell = conv2 output relative to the agent's first reachable one,
+// zeros where it has none), so a row (class k, agent m) is an affine gather like SlotGatherT3P's: tap (ty, tx) reads cell
+// (iy0 + ty, ix0 + tx), rowdesc = {element offset of tap (0, 0), (iy0 << 16) | (ix0 & 0xffff)}; invalid rows carry iy0 = ix0 = -16.
+// Group semantics (one class per npad rows, its own bnstep-row block of Bt, row ranges per class) as DenseRowsGroups.
+struct T2SlotGather {
+    static constexpr bool kRelu = false;
+    const float *base;
+    const int2 *rowdesc;
+    int rows, npad, nlive, bnstep, cpc;
+    __device__ __forceinline__ int K() const { return 256; }
+    __device__ __forceinline__ void rowh(int2 d, long &off, int &iy0, int &ix0) const {
+        off = d.x;
+        iy0 = d.y >> 16;
+        ix0 = (int)(int16_t)(d.y & 0xFFFF);
+    }
+    __device__ __forceinline__ void row(int r, long &off, int &iy0, int &ix0) const { rowh(rowdesc[r], off, iy0, ix0); }
+    __device__ __forceinline__ void tap(int k0, int &toff, int &ty, int &tx) const {
+        const int t = k0 >> 6, c0 = k0 & 63;
+        ty = t >> 1;
+        tx = t & 1;
+        toff = (ty * 3 + tx) * 64 + c0;
+    }
+    __device__ __forceinline__ bool ok(int iy0, int ix0, int ty, int tx) const { return (unsigned)(iy0 + ty) < 3u && (unsigned)(ix0 + tx) < 3u; }
+    __device__ __forceinline__ bool tile_ok(int, int) const { return true; }
+    __device__ __forceinline__ bool tile_active(int m0) const { return m0 % npad < nlive; }
+    __device__ __forceinline__ int bk(int k0, int) const { return k0; }
+    __device__ __forceinline__ int bn(int n0, int m0) const { return n0 + (m0 / npad) * bnstep; }
+    __device__ __forceinline__ int2 ahandle(int m) const { return rowdesc[m]; }
+    __device__ __forceinline__ bool hvalid(int2) const { return true; }      // the offset of tap (0,0) may be negative
+    __device__ __forceinline__ int bhandle(int m) const { return m; }
+    __device__ __forceinline__ void mrange(int z, int mc, int &mbeg, int &mend) const {
+        const int g = z / cpc, c = z - g * cpc;
+        mbeg = g * npad + c * mc;
+        mend = min(g * npad + nlive, mbeg + mc);
+    }
+};
+
 // Two row-major [rows][ld] operands side by side along K (k < half from base, k >= half from base + delta), multiplied against
 // two weight matrices stacked the same way (Bt's k offset jumps by bdelta at k = half): dX = [dY1 | dY2] . [W1 | W2]^T in one
 // pass instead of two accumulating ones (pol1 / v1 both feed dense2's output).
