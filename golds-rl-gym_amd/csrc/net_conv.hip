@@ -97,6 +97,7 @@ struct NetLane {
     unsigned *tamask, *tbmask, *tcmask, *tnmask;      // (tnmask: blocks of sraw anybody reads) + 100-bit mask of touched 2x2 conv1 pixel blocks, 49-bit mask of affected conv3 outputs
     int *trowlist, *tblklist, *tc3list, *trows_n, *twgcnt, *twgoff;      // their lists, live counts [conv2 rows, blocks, conv3 rows], scan scratch
     unsigned *tumask;          // union of the chunk's conv3 masks (2 words)
+    unsigned *tneed2;          // conv2 pixels inside the 3 x 3 windows of that union (3 words): what conv3 reads of a2sh
     float *tubias;             // dense1's per-env bias under that union (trunk_ubias_kernel)
     float *tug, *tuspix;       // gradient side: G = column sums of gd1sh (512), per-pixel closed-form sums (49 x 64)
     float *tslab, *tsums;      // tslab: per-workgroup sums of dz2 over unaffected rows; tsums: [dz2 total 64 | unaffected 64]
@@ -791,6 +792,7 @@ static int alloc_lane_forward(grl_net *n) {
     if (rc == GRL_OK) rc = nalloc(n, &n->twgcnt, ((c / 10 + TRUNK_ENVS - 1) / TRUNK_ENVS + 1) * 3);
     if (rc == GRL_OK) rc = nalloc(n, &n->twgoff, ((c / 10 + TRUNK_ENVS - 1) / TRUNK_ENVS + 1) * 3);
     if (rc == GRL_OK) rc = nalloc(n, &n->tumask, 4);
+    if (rc == GRL_OK) rc = nalloc(n, &n->tneed2, 4);
     if (rc == GRL_OK) rc = nalloc(n, &n->tubias, 512);
     if (rc == GRL_OK) rc = nalloc(n, &n->tug, 512);
     if (rc == GRL_OK) rc = nalloc(n, &n->tuspix, 49 * 64);
@@ -1137,6 +1139,9 @@ static int read_activation_impl(grl_net *n, const char *which, float *host, size
         if (n->last_n <= 0) return nfail(n, GRL_E_STATE, "grl_net_read_activation: no forward pass yet");
         float *tmp = nullptr;
         NET_HIP(n, hipMalloc((void **)&tmp, need_a));
+        if (n->trunk_skip && n->expand2_gemm)      // list form: the pixels no consumer reads were not filled; they hold the background row (debug/test access)
+            hipLaunchKernelGGL(trunk_fill_kernel, dim3((n->last_n / 10 * 81 * 16 + 255) / 256), dim3(256), 0, n->h->stream, (const unsigned *)n->tamask, 3, 81,
+                               (const float *)(n->tbgz + 64), n->last_n / 10 * 81, n->a2sh, (const float *)nullptr, (float *)nullptr, 0, (const unsigned *)nullptr);
         hipLaunchKernelGGL(materialize_a2_kernel, dim3(n->last_n), dim3(256), 0, n->h->stream, n->a2sh, n->d2s, n->m2s, n->ulist, n->sbase, tmp);
         hipError_t e1 = hipStreamSynchronize(n->h->stream), e2 = hipMemcpy(host, tmp, bytes, hipMemcpyDeviceToHost);
         (void)hipFree(tmp);
@@ -1150,6 +1155,8 @@ static int read_activation_impl(grl_net *n, const char *which, float *host, size
         if (n->last_n <= 0) return nfail(n, GRL_E_STATE, "grl_net_read_activation: no forward pass yet");
         float *tmp = nullptr;
         NET_HIP(n, hipMalloc((void **)&tmp, need_a));
+        if (n->trunk_skip && n->expand2_gemm)
+            hipLaunchKernelGGL(materialize_a3sh_kernel, dim3(n->last_n / 10), dim3(256), 0, n->h->stream, (const unsigned *)n->tumask, (const float *)(n->tbgz3 + 64), n->a3sh);
         hipLaunchKernelGGL(materialize_a3_kernel, dim3(n->last_n), dim3(256), 0, n->h->stream, n->a3sh, n->d3, n->m3, n->org, n->patch_skip ? n->smask : nullptr, tmp);
         hipError_t e1 = hipStreamSynchronize(n->h->stream), e2 = hipMemcpy(host, tmp, bytes, hipMemcpyDeviceToHost);
         (void)hipFree(tmp);
