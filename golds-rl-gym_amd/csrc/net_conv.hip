@@ -888,7 +888,7 @@ int grl_net_create(grl_handle *h, const grl_net_config *cfg, grl_net **out) {
         const char *e2 = getenv("GRL_NET_EXPAND2");
         n->expand2_gemm = (e2 && strcmp(e2, "lds") == 0) ? 0 : 1;
     }
-    n->pslice_rows = PATCH_SLICE_ROWS; n->pwgrad_xcd = 2;
+    n->pslice_rows = PATCH_SLICE_ROWS; n->pwgrad_xcd = 1;      // a row slice per XCD: A and B of a slice fetched once (under the support masks and the lighter traffic of round 3 this order wins by 0.7 %; 2 was the choice for the plain patch)
     if (const char *e = getenv("GRL_PATCH_SLICE")) { const int v = atoi(e); if (v == 256 || v == 512 || v == 1024 || v == 2048 || v == 4096 || v == 8192) n->pslice_rows = v; }
     if (const char *e = getenv("GRL_PATCH_WGRAD_XCD")) n->pwgrad_xcd = atoi(e);
     n->pdgrad_xcd = 1;      // M tile per XCD (A fetched once): 40.6 -> 38.5 ms per update at 81 920-sample chunks; spread (0) was faster at 40 960
