@@ -349,8 +349,9 @@ struct DenseRowsGroups {
 // The class-major operand of conv2's per-agent corrections WITHOUT its copy in memory (round 3; gather_t2_kernel used to write
 // at2[k][m][(ty, tx, co)] = the agent's masked dz2 row at conv2 output o(ty, tx), 335 MB per chunk, read back twice).  The agent's
 // rows now sit in a canonical 3 x 3 grid dza[m][sy][sx][64] (cell = conv2 output relative to the agent's first reachable one,
-// zeros where it has none), so a row (class k, agent m) is an affine gather like SlotGatherT3P's: tap (ty, tx) reads cell
-// (iy0 + ty, ix0 + tx), rowdesc = {element offset of tap (0, 0), (iy0 << 16) | (ix0 & 0xffff)}; invalid rows carry iy0 = ix0 = -16.
+// nothing written where it has none), so a row (class k, agent m) is an affine gather like SlotGatherT3P's: tap (ty, tx) reads cell
+// (iy0 + ty, ix0 + tx) if that cell exists, rowdesc = {element offset of tap (0, 0), (iy0 << 16) | nr << 12 | nc << 8 | (ix0 & 0xff)}
+// with nr x nc the agent's slot rectangle; invalid rows carry nr = nc = 0.
 // Group semantics (one class per npad rows, its own bnstep-row block of Bt, row ranges per class) as DenseRowsGroups.
 struct T2SlotGather {
     static constexpr bool kRelu = false;
@@ -370,7 +371,10 @@ struct T2SlotGather {
         tx = t & 1;
         toff = (ty * 3 + tx) * 64 + c0;
     }
-    __device__ __forceinline__ bool ok(int iy0, int ix0, int ty, int tx) const { return (unsigned)(iy0 + ty) < 3u && (unsigned)(ix0 + tx) < 3u; }
+    __device__ __forceinline__ bool ok(int iy0, int ixp, int ty, int tx) const {      // ixp: nr << 12 | nc << 8 | (ix0 & 0xff)
+        const int ix0 = (int)(int8_t)(ixp & 0xFF), nc = (ixp >> 8) & 15, nr = (ixp >> 12) & 15;
+        return (unsigned)(iy0 + ty) < (unsigned)nr && (unsigned)(ix0 + tx) < (unsigned)nc;
+    }
     __device__ __forceinline__ bool tile_ok(int, int) const { return true; }
     __device__ __forceinline__ bool tile_active(int m0) const { return m0 % npad < nlive; }
     __device__ __forceinline__ int bk(int k0, int) const { return k0; }
