@@ -178,6 +178,7 @@ int grl_config_default(int32_t env_kind, grl_config *cfg) {
     cfg->seed = 1692;
     cfg->solow_sigma = 0.1; cfg->solow_delta = 0.02;      // fed_env.py:166
     cfg->trade_std_p = 0.05;                              // fed_env.py:269
+    cfg->trade_starting_balance = 10.0;                   // fed_env.py:269
     return GRL_OK;
 }
 
@@ -193,6 +194,8 @@ int grl_create(const grl_config *cfg, grl_handle **out) {
     if (cfg->num_envs <= 0) return fail(nullptr, GRL_E_INVALID, "grl_create: num_envs must be positive");
     if (cfg->env_kind == GRL_ENV_SWARM && (cfg->grid_size < 2 || cfg->grid_size > 254)) return fail(nullptr, GRL_E_INVALID, "grl_create: grid_size must be in 2..254");
     if (cfg->env_kind == GRL_ENV_TRADE && (cfg->n_assets < 1 || cfg->n_assets > 64)) return fail(nullptr, GRL_E_INVALID, "grl_create: n_assets must be in 1..64");
+    if (cfg->env_kind == GRL_ENV_TRADE && !(cfg->trade_starting_balance > 0.0 && cfg->trade_starting_balance < 1e300))
+        return fail(nullptr, GRL_E_INVALID, "grl_create: trade_starting_balance must be a positive finite number (the observation takes log(cash + 1e-4))");
     if (cfg->env_kind == GRL_ENV_SOLOW) {
         if (cfg->solow_p < 1 || cfg->solow_p > 8) return fail(nullptr, GRL_E_INVALID, "grl_create: solow_p must be in 1..8 (p=0 cannot reset in the reference either: fed_env.py:250 indexes an empty z)");
         if (cfg->solow_q < 0 || cfg->solow_q > 8) return fail(nullptr, GRL_E_INVALID, "grl_create: solow_q must be in 0..8");
@@ -388,6 +391,28 @@ int grl_swarm_step_f64(grl_handle *h, const double *actions_host) {
     }
     GRL_HIP(h, hipMemcpyAsync(h->sw.act64, actions_host, bytes, hipMemcpyHostToDevice, h->stream));
     int rc = swarm_launch_step(h, nullptr, h->sw.act64);
+    if (rc == GRL_OK) rc = episodes_launch_account(h);
+    if (rc == GRL_OK) h->step_in_flight = true;
+    return rc;
+}
+
+int grl_swarm_step_opts(grl_handle *h, const void *actions_host, int32_t actions_f64, int32_t add_wind) {
+    if (!h || !actions_host) return fail(h, GRL_E_INVALID, "grl_swarm_step_opts: null argument");
+    if (h->cfg.env_kind != GRL_ENV_SWARM) return fail(h, GRL_E_INVALID, "grl_swarm_step_opts: not a Swarm handle");
+    hipSetDevice(h->cfg.device_id);
+    int rc;
+    if (actions_f64) {
+        const size_t bytes = (size_t)h->E * N_AGENTS * 2 * sizeof(double);
+        if (!h->sw.act64) {
+            GRL_HIP(h, hipMalloc((void **)&h->sw.act64, bytes));
+            h->allocs.push_back(h->sw.act64);
+        }
+        GRL_HIP(h, hipMemcpyAsync(h->sw.act64, actions_host, bytes, hipMemcpyHostToDevice, h->stream));
+        rc = swarm_launch_step(h, nullptr, h->sw.act64, add_wind ? 0 : 1);
+    } else {
+        GRL_HIP(h, hipMemcpyAsync(h->actions, actions_host, h->actions_elems * 4, hipMemcpyHostToDevice, h->stream));
+        rc = swarm_launch_step(h, h->actions, nullptr, add_wind ? 0 : 1);
+    }
     if (rc == GRL_OK) rc = episodes_launch_account(h);
     if (rc == GRL_OK) h->step_in_flight = true;
     return rc;

@@ -47,6 +47,7 @@ struct TradeState {
     int32_t *nhist;                   // states in the (PAAC-style) worker history list, as SolowState::nhist
     float *obs_raw, *obs;             // (E,1+2n)
     double std_e;
+    double start;                     // starting_balance (fed_env.py:269,323-326)
 };
 
 struct TickerState {
@@ -117,7 +118,7 @@ int hip_fail(grl_handle *h, hipError_t e, const char *what);
 int episodes_launch_account(grl_handle *h, int env_base = 0, int count = -1);
 // swarm.hip
 int swarm_alloc(grl_handle *h);
-int swarm_launch_step(grl_handle *h, const float *actions_dev, const double *actions64_dev = nullptr);
+int swarm_launch_step(grl_handle *h, const float *actions_dev, const double *actions64_dev = nullptr, int no_wind = 0);
 int swarm_launch_step_range(grl_handle *h, const float *actions_dev, int env_base, int count, int slot);
 int swarm_launch_reset(grl_handle *h, const int32_t *list_dev, const int32_t *count_dev, int max_count);
 int swarm_launch_observe(grl_handle *h);

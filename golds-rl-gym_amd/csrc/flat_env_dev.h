@@ -160,6 +160,7 @@ struct TradeParams {
     const int32_t *reset_list, *reset_count;
     int E, n, max_steps;
     double std_e;
+    double start;                     // TradeAR1Env.starting_balance: cash = assets = start after a reset (fed_env.py:323-326)
     uint32_t flags, env_off;
     uint64_t seed;
 };
@@ -174,7 +175,7 @@ static inline TradeParams trade_params(grl_handle *h) {
     R.nstep = h->tr.nstep; R.nhist = h->tr.nhist; R.rnn = h->cfg.rnn_length; R.elapsed = h->elapsed; R.episode = h->episode; R.reward = h->reward; R.done = h->done;
     R.obs_raw = h->tr.obs_raw; R.obs = h->tr.obs; R.done_list = h->done_list; R.done_count = h->done_count;
     R.err_flag = h->err_flag; R.E = h->E; R.n = h->cfg.n_assets; R.max_steps = h->cfg.max_episode_steps;
-    R.std_e = h->tr.std_e; R.flags = h->cfg.flags; R.env_off = (uint32_t)h->cfg.env_id_offset; R.seed = h->cfg.seed;
+    R.std_e = h->tr.std_e; R.start = h->tr.start; R.flags = h->cfg.flags; R.env_off = (uint32_t)h->cfg.env_id_offset; R.seed = h->cfg.seed;
     return R;
 }
 

@@ -159,8 +159,8 @@ __global__ __launch_bounds__(256) void trade_step_kernel(TradeParams R) {
         R.nstep[env] = st + 1;
         float *oraw = R.obs_raw + (size_t)env * S, *o = R.obs + (size_t)env * S;
         if (done) {   // auto-reset (emulator_runner.py:50-52) -> TradeAR1Env._reset (fed_env.py:323-330)
-            cash = 10.0;
-            R.assets[env] = 10.0;
+            cash = R.start;
+            R.assets[env] = R.start;
             R.elapsed[env] = 0;
             R.nhist[env] = 1;            // histories[i] = [reset state]  (emulator_runner.py:52)
             R.episode[env] = R.episode[env] + 1;
@@ -211,10 +211,10 @@ __global__ void trade_reset_kernel(TradeParams R) {
     const int env = R.reset_list[li];
     const int n = R.n, S = 1 + 2 * n;
     const size_t E = R.E;
-    R.cash[env] = 10.0; R.assets[env] = 10.0; R.elapsed[env] = 0; R.episode[env] = R.episode[env] + 1;
+    R.cash[env] = R.start; R.assets[env] = R.start; R.elapsed[env] = 0; R.episode[env] = R.episode[env] + 1;
     R.nhist[env] = 0;     // explicit reset: the worker's list starts empty (emulator_runner.py:23)
     float *oraw = R.obs_raw + (size_t)env * S, *o = R.obs + (size_t)env * S;
-    oraw[0] = 10.f; o[0] = trade_proc(0, 10.0);
+    oraw[0] = (float)R.start; o[0] = trade_proc(0, R.start);
     for (int a = 0; a < n; ++a) {
         R.q[a * E + env] = 0.0; R.p[a * E + env] = 1.0;
         oraw[1 + a] = 0.f; oraw[1 + n + a] = 1.f;
@@ -241,6 +241,7 @@ int trade_alloc(grl_handle *h) {
     size_t E = h->E, n = h->cfg.n_assets;
     double sp = h->cfg.trade_std_p;
     h->tr.std_e = sqrt((sp * sp) * (1 - 0.9 * 0.9));   // fed_env.py:277-278
+    h->tr.start = h->cfg.trade_starting_balance;
     int rc;
     if ((rc = dmalloc(h, &h->tr.cash, E))) return rc;
     if ((rc = dmalloc(h, &h->tr.assets, E))) return rc;

@@ -61,6 +61,7 @@ using GatherT2 = ConvGather<10, 10, 1, 1, -1, -1, 2, 2, 64, 9, 9, true>;      //
 // use_lane() swaps the whole pointer set between chunk enqueues (host-side, sequential).
 constexpr int GRL_MAX_LANES = 8;
 constexpr int kLossScaleAt = 8, kLossBoundAt = 10;      // slots of grl_net::stats (net_train.inc: loss scale)
+constexpr int kRangeLatchAt = 12;                        // int: the range flag of a gradient pass, latched before the post-update background pass (train_apply)
 struct NetLane {
     float *grads;              // this lane's gradient accumulator (lane 0's is THE gradient; lane 1's is added before the all-reduce)
     // forward activations (chunk)
@@ -1174,6 +1175,8 @@ static int read_activation_impl(grl_net *n, const char *which, float *host, size
     else if (w == "gp1") { src = n->gp1; per = 512; }
     else if (w == "gv2") { src = n->gv2; per = 256; }
     else if (w == "gd2") { src = n->gd2; per = 256; }
+    else if (w == "gv1") { src = n->gv1; per = 512; }
+    else if (w == "gd1") { src = n->gd1; per = 512; }
     else return nfail(n, GRL_E_INVALID, "grl_net_read_activation: unknown tensor '" + w + "'");
     size_t need = (size_t)n->last_n * per * 4;
     if (bytes != need) return nfail(n, GRL_E_SIZE, "grl_net_read_activation: need " + std::to_string(need) + " bytes");

@@ -31,6 +31,7 @@ struct SwarmParams {
     int env_base;                // MODE_STEP / MODE_OBSERVE: the launch covers envs [env_base, E) (E = end of the range)
     uint32_t flags, env_off;
     uint64_t seed;
+    int no_wind;                 // MODE_STEP: SwarmEnv._step(v_action, add_wind=False) -- the agents' action row is used as it is (multiagent.py:33-36)
 };
 
 constexpr int LDS_STRIDE = 97;   // 90 points padded so two envs' rows start on different banks
@@ -136,12 +137,14 @@ __device__ __forceinline__ void locust_velocity(const double2 *src, double xj, d
 // On return L.p holds the new positions of all 90 points, L.rew[el] the reward; ends on a barrier.
 template <bool FAST>
 __device__ __forceinline__ void block_step(SwarmLds &L, int tid, int el, int j, double &xj, double &yj, double actx,
-                                           double acty, double anx, double any, double pnx, double pny, bool act32 = false) {
+                                           double acty, double anx, double any, double pnx, double pny, bool act32 = false,
+                                           bool wind = true) {
     if (tid < SWARM_EPB * N_AGENTS) {
         int ea = tid / N_AGENTS, a = tid - ea * N_AGENTS;
         double2 q = L.p[ea][N_LOCUSTS + a];
-        if (act32) x_update_f32v(q.x, q.y, (float)actx + 1.0f, (float)acty, anx, any);
-        else x_update(q.x, q.y, actx + WIND, acty, anx, any);   // wind: multiagent.py:35-36
+        // wind: `if add_wind: v_action[:, 0] += WIND_SPEED` (multiagent.py:35-36); the locusts' U in v_calculate does not depend on it
+        if (act32) x_update_f32v(q.x, q.y, wind ? (float)actx + 1.0f : (float)actx, (float)acty, anx, any);
+        else x_update(q.x, q.y, wind ? actx + WIND : actx, acty, anx, any);
         L.p[ea][N_LOCUSTS + a] = q;
     }
     L.p[el][j] = make_double2(xj, yj);
@@ -243,7 +246,7 @@ __global__ __launch_bounds__(SWARM_TPB) void swarm_kernel(SwarmParams P) {
             double2 n = reinterpret_cast<const double2 *>(P.anoise)[(size_t)aenv * N_AGENTS + a];
             anx = n.x; any = n.y;
         }
-        block_step<FAST>(L, tid, el, j, xj, yj, actx, acty, anx, any, pnx, pny, P.actions64 == nullptr);
+        block_step<FAST>(L, tid, el, j, xj, yj, actx, acty, anx, any, pnx, pny, P.actions64 == nullptr, P.no_wind == 0);
         if (active) reinterpret_cast<double2 *>(P.x)[(size_t)env * N_LOCUSTS + j] = make_double2(xj, yj);
         if (aactive) reinterpret_cast<double2 *>(P.xa)[(size_t)aenv * N_AGENTS + a] = L.p[ea][N_LOCUSTS + a];
         if (active && j == 0) {
@@ -482,10 +485,11 @@ int swarm_alloc(grl_handle *h) {
 
 static inline int nblocks(int n) { return (n + SWARM_EPB - 1) / SWARM_EPB; }
 
-int swarm_launch_step(grl_handle *h, const float *actions_dev, const double *actions64_dev) {
+int swarm_launch_step(grl_handle *h, const float *actions_dev, const double *actions64_dev, int no_wind) {
     SwarmParams P = make_params(h);
     P.actions = actions_dev;
     P.actions64 = actions64_dev;
+    P.no_wind = no_wind;
     GRL_HIP(h, hipMemsetAsync(h->done_count, 0, sizeof(int32_t), h->stream));
     prof_begin(h);
     if (h->cfg.flags & GRL_F_SWARM_FAST_MATH)

@@ -28,7 +28,7 @@ class GrlConfig(C.Structure):
         ("max_episode_steps", C.c_int32), ("grid_size", C.c_int32), ("n_assets", C.c_int32), ("solow_p", C.c_int32),
         ("solow_q", C.c_int32), ("solow_tape_len", C.c_int32), ("rnn_length", C.c_int32), ("flags", C.c_uint32),
         ("seed", C.c_uint64), ("env_id_offset", C.c_int64), ("solow_sigma", C.c_double), ("solow_delta", C.c_double),
-        ("trade_std_p", C.c_double),
+        ("trade_std_p", C.c_double), ("trade_starting_balance", C.c_double),
     ]
 
 
@@ -83,6 +83,7 @@ SIGNATURES = {
     "grl_timer_stop": (C.c_int, [_P]),
     "grl_timer_ms": (C.c_int, [_P, C.POINTER(C.c_float)]),
     "grl_swarm_step_f64": (C.c_int, [_P, _P]),
+    "grl_swarm_step_opts": (C.c_int, [_P, _P, _I, _I]),
     "grl_episodes_enable": (C.c_int, [_P, _I]),
     "grl_episodes_read": (C.c_int, [_P, _P, _I, C.POINTER(_I), C.POINTER(_I)]),
     "grl_episodes_running": (C.c_int, [_P, _P, _P]),
@@ -197,6 +198,17 @@ class Engine(object):
         if a.shape != (self.E, 10, 2):
             raise ValueError("swarm_step_f64: expected shape %s, got %s" % ((self.E, 10, 2), a.shape))
         self._check(self.lib.grl_swarm_step_f64(self.h, _ptr(a)))
+        self.wait()
+
+    def swarm_step_opts(self, actions, add_wind=True):
+        """SwarmEnv._step(v_action, add_wind) (multiagent.py:30-36): float32 actions keep the worker's float32 arithmetic, anything
+        else is stepped as float64; synchronous like step()."""
+        a = np.asarray(actions)
+        f64 = a.dtype != np.float32
+        a = np.ascontiguousarray(a, dtype=np.float64 if f64 else np.float32)
+        if a.shape != (self.E, 10, 2):
+            raise ValueError("swarm_step_opts: expected shape %s, got %s" % ((self.E, 10, 2), a.shape))
+        self._check(self.lib.grl_swarm_step_opts(self.h, _ptr(a), 1 if f64 else 0, 1 if add_wind else 0))
         self.wait()
 
     def swarm_reset_injected(self, x0, xa0, random_actions, agent_noise, particle_noise):

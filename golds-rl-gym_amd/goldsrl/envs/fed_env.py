@@ -55,13 +55,14 @@ class TradeAR1Env(object):
     """n-asset portfolio env with log-AR(1) prices (fed_env.py:268-334)."""
 
     def __init__(self, starting_balance=10., base_rate=0.05, n_assets=2, std_p=0.05, max_episode_steps=None, device_id=0, seed=1692):
-        if starting_balance != 10.:
-            raise NotImplementedError("only the reference default starting_balance=10 is supported")
         self.MIN_CASH = 1.
+        self.starting_balance = starting_balance
+        self.r = base_rate                      # kept and never used, as in the reference (fed_env.py:275)
         self.n_assets = n_assets
         self.rho_p = 0.9
         self.std_e = np.sqrt((std_p ** 2) * (1 - self.rho_p ** 2))
         self._eng = _ffi.Engine(_ffi.ENV_TRADE, 1, device_id=device_id, seed=int(seed), n_assets=n_assets, trade_std_p=std_p,
+                                trade_starting_balance=float(starting_balance),
                                 max_episode_steps=int(max_episode_steps or 0))
 
     def reset(self):

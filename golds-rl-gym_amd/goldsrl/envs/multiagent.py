@@ -67,10 +67,10 @@ class SwarmEnv(object):
         return self.states
 
     def _step(self, v_action, add_wind=True):
-        if not add_wind:
-            raise NotImplementedError("add_wind=False is never used by the reference's callers")
         v_action = np.asarray(v_action)
-        if v_action.dtype == np.float32:       # what the worker reads from the float32 shared array (quirk Q7)
+        if not add_wind:                        # multiagent.py:35-36 skipped: the agents move by the action alone
+            self._eng.swarm_step_opts(v_action.reshape(1, self.N_AGENTS, 2), add_wind=False)
+        elif v_action.dtype == np.float32:      # what the worker reads from the float32 shared array (quirk Q7)
             self._eng.step(v_action.reshape(1, self.N_AGENTS, 2))
         else:                                   # a direct caller's float64 actions are used as they are (multiagent.py:30-44)
             self._eng.swarm_step_f64(v_action.astype(np.float64).reshape(1, self.N_AGENTS, 2))

@@ -93,6 +93,7 @@ typedef struct grl_config {
     double solow_sigma;        /* 0.1 */
     double solow_delta;        /* 0.02 */
     double trade_std_p;        /* 0.05 */
+    double trade_starting_balance; /* TradeAR1Env(starting_balance=10.) (fed_env.py:269,323-326): cash and assets after every reset; > 0 */
 } grl_config;
 
 typedef struct grl_handle grl_handle;
@@ -191,6 +192,10 @@ int grl_step_device(grl_handle *h, const float *actions_dev);
  * through the float32 shared array (quirk Q7) and use grl_step_async.  The dynamics are chaotic (~1.15x per step), so a
  * float32-rounded action shows up as 4e-4 in the reward after 128 steps. */
 int grl_swarm_step_f64(grl_handle *h, const double *actions_host);
+/* Swarm only: SwarmEnv._step(v_action, add_wind) with both of its knobs (multiagent.py:30-36): actions_host is (E,10,2) float64
+ * (actions_f64 != 0) or float32; add_wind = 0 skips `v_action[:, 0] += WIND_SPEED` for the agents (the locusts' U term of
+ * v_calculate, multiagent.py:39, does not depend on it).  add_wind = 1 is grl_step_async / grl_swarm_step_f64. */
+int grl_swarm_step_opts(grl_handle *h, const void *actions_host, int32_t actions_f64, int32_t add_wind);
 int grl_wait(grl_handle *h);                       /* hipStreamSynchronize + deferred error checks */
 int grl_outputs(grl_handle *h, grl_out_ptrs *out); /* device pointers */
 /* Copy one output to the host: which = name of a grl_out_ptrs member, e.g. "reward". */

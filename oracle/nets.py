@@ -153,37 +153,118 @@ def gaussian_loss_terms(mu, sigma, actions, advantages, critic_target, vs, beta,
     return policy_loss + critic_loss_mean, policy_loss, critic_loss_mean, dmu, dsigma, dvs
 
 
-def conv_loss_and_grads(p, states, actions, advantages, critic_target, beta, scale):
-    """loss and d loss / d params for N1 (float64)."""
-    mu, sigma, vs, c = conv_forward(p, states, scale, keep=True)
-    loss, pl, cl, dmu, dsigma, dvs = gaussian_loss_terms(mu, sigma, actions, advantages, critic_target, vs, beta, scale)
+RELU_LAYERS = ("a1", "a2", "a3", "d1", "d2", "p1", "v1", "v2")
+
+
+def _conv_backward(p, c, mu, sigma, dmu, dsigma, dvs, m, scale):
+    """d loss / d params of N1 from the head gradients, the forward cache c and the ReLU derivative masks m."""
     g = {}
     dzmu = dmu * (1 - mu ** 2)
     dzsig = dsigma * sigma * (1 - sigma)
     g["mu_w"], g["mu_b"] = c["p1"].T @ dzmu, dzmu.sum(0)
     g["sigma_w"], g["sigma_b"] = c["p1"].T @ dzsig, dzsig.sum(0)
-    dp1 = (dzmu @ p["mu_w"].T + dzsig @ p["sigma_w"].T) * (c["p1"] > 0)
+    dp1 = (dzmu @ p["mu_w"].T + dzsig @ p["sigma_w"].T) * m["p1"]
     g["pol1_w"], g["pol1_b"] = c["d2"].T @ dp1, dp1.sum(0)
     dzv = (dvs * (-scale) * _sigmoid(c["zv"]))[:, None]
     g["v3_w"], g["v3_b"] = c["v2"].T @ dzv, dzv.sum(0)
-    dv2 = (dzv @ p["v3_w"].T) * (c["v2"] > 0)
+    dv2 = (dzv @ p["v3_w"].T) * m["v2"]
     g["v2_w"], g["v2_b"] = c["v1"].T @ dv2, dv2.sum(0)
-    dv1 = (dv2 @ p["v2_w"].T) * (c["v1"] > 0)
+    dv1 = (dv2 @ p["v2_w"].T) * m["v1"]
     g["v1_w"], g["v1_b"] = c["d2"].T @ dv1, dv1.sum(0)
-    dd2 = (dp1 @ p["pol1_w"].T + dv1 @ p["v1_w"].T) * (c["d2"] > 0)
+    dd2 = (dp1 @ p["pol1_w"].T + dv1 @ p["v1_w"].T) * m["d2"]
     g["dense2_w"], g["dense2_b"] = c["d1"].T @ dd2, dd2.sum(0)
-    dd1 = (dd2 @ p["dense2_w"].T) * (c["d1"] > 0)
+    dd1 = (dd2 @ p["dense2_w"].T) * m["d1"]
     g["dense1_w"], g["dense1_b"] = c["flat"].T @ dd1, dd1.sum(0)
-    da3 = (dd1 @ p["dense1_w"].T).reshape(c["a3"].shape) * (c["a3"] > 0)
+    da3 = (dd1 @ p["dense1_w"].T).reshape(c["a3"].shape) * m["a3"]
     g["conv3_w"] = (c["cols3"].reshape(-1, c["cols3"].shape[-1]).T @ da3.reshape(-1, 64)).reshape(p["conv3_w"].shape)
     g["conv3_b"] = da3.sum(axis=(0, 1, 2))
-    da2 = _col2im(da3 @ p["conv3_w"].reshape(-1, 64).T, c["a2"].shape, 3, 3, 1) * (c["a2"] > 0)
+    da2 = _col2im(da3 @ p["conv3_w"].reshape(-1, 64).T, c["a2"].shape, 3, 3, 1) * m["a2"]
     g["conv2_w"] = (c["cols2"].reshape(-1, c["cols2"].shape[-1]).T @ da2.reshape(-1, 64)).reshape(p["conv2_w"].shape)
     g["conv2_b"] = da2.sum(axis=(0, 1, 2))
-    da1 = _col2im(da2 @ p["conv2_w"].reshape(-1, 64).T, c["a1"].shape, 4, 4, 2) * (c["a1"] > 0)
+    da1 = _col2im(da2 @ p["conv2_w"].reshape(-1, 64).T, c["a1"].shape, 4, 4, 2) * m["a1"]
     g["conv1_w"] = (c["cols1"].reshape(-1, c["cols1"].shape[-1]).T @ da1.reshape(-1, 32)).reshape(p["conv1_w"].shape)
     g["conv1_b"] = da1.sum(axis=(0, 1, 2))
-    return loss, pl, cl, g, (mu, sigma, vs)
+    return g
+
+
+def conv_loss_and_grads(p, states, actions, advantages, critic_target, beta, scale, flip=None):
+    """loss and d loss / d params for N1 (float64).
+    flip: optional list of (layer, flat index into that layer's activation array) whose ReLU DERIVATIVE is inverted in the backward
+    pass (the forward values stay): what a float32 evaluation does when it puts a pre-activation that float64 sees within
+    round-off of zero on the other side (relu_ambiguous / explain_by_relu_flips below)."""
+    mu, sigma, vs, c = conv_forward(p, states, scale, keep=True)
+    loss, pl, cl, dmu, dsigma, dvs = gaussian_loss_terms(mu, sigma, actions, advantages, critic_target, vs, beta, scale)
+    m = {k: c[k] > 0 for k in RELU_LAYERS}
+    for layer, idx in (flip or ()):
+        m[layer].reshape(-1)[idx] ^= True
+    return loss, pl, cl, _conv_backward(p, c, mu, sigma, dmu, dsigma, dvs, m, scale), (mu, sigma, vs)
+
+
+# float32 evaluations differ from float64 by ~5e-7 of a layer's largest value in the GEMM layers (measured, DESIGN.md section 3); conv1
+# is a sum of <= 91 products per pixel
+RELU_EPS = {"a1": 3e-7, "a2": 2e-6, "a3": 2e-6, "d1": 2e-6, "d2": 2e-6, "p1": 2e-6, "v1": 2e-6, "v2": 2e-6}
+
+
+def relu_ambiguous(p, states, eps=None, batch=128):
+    """ReLU inputs of N1 that float64 sees within eps[layer] * (the layer's largest |pre-activation|) of zero: where a float32
+    evaluation may legitimately take the other branch.  Returns a list of (sample, layer, flat index inside the sample's
+    activation, z)."""
+    eps = RELU_EPS if eps is None else (eps if isinstance(eps, dict) else {k: eps for k in RELU_LAYERS})
+    out = []
+    for s0 in range(0, states.shape[0], batch):
+        x = states[s0:s0 + batch]
+        z = {}
+        z["a1"], _ = _conv(x, p["conv1_w"], p["conv1_b"], 4); a = np.maximum(z["a1"], 0)
+        z["a2"], _ = _conv(a, p["conv2_w"], p["conv2_b"], 2); a = np.maximum(z["a2"], 0)
+        z["a3"], _ = _conv(a, p["conv3_w"], p["conv3_b"], 1); a = np.maximum(z["a3"], 0)
+        z["d1"] = a.reshape(a.shape[0], -1) @ p["dense1_w"] + p["dense1_b"]; d1 = np.maximum(z["d1"], 0)
+        z["d2"] = d1 @ p["dense2_w"] + p["dense2_b"]; d2 = np.maximum(z["d2"], 0)
+        z["p1"] = d2 @ p["pol1_w"] + p["pol1_b"]
+        z["v1"] = d2 @ p["v1_w"] + p["v1_b"]; v1 = np.maximum(z["v1"], 0)
+        z["v2"] = v1 @ p["v2_w"] + p["v2_b"]
+        for layer in RELU_LAYERS:
+            zl = z[layer].reshape(x.shape[0], -1)
+            near = np.argwhere(np.abs(zl) < eps[layer] * np.abs(zl).max())
+            out.extend((s0 + int(i), layer, int(j), float(zl[i, j])) for i, j in near)
+    return out
+
+
+def explain_by_relu_flips(p, states, actions, advantages, critic_target, beta, scale, got_flat, g_ref, eps=None):
+    """Compares a float32 gradient (flat vector) with the float64 one up to the ReLU decisions float32 cannot be held to.
+    A sample's pre-activation within round-off of zero may fall on either side in float32; its derivative mask then flips and the
+    gradient moves by that element's whole contribution -- 1e-3 of a block's largest entry is typical at ~1000 samples -- although
+    nothing is wrong.  For every ambiguous element j (relu_ambiguous) the exact gradient change D_j of flipping it is computed from
+    the one sample it belongs to; got - ref is then fitted by sum_j s_j D_j (least squares; elements of one conv1 pixel shared by an
+    env's agents give proportional columns, so single coefficients are not unique).  Returns (residual as a dict of blocks, the
+    coefficients s, the ambiguous list): a correct float32 gradient leaves a residual at float32 level."""
+    N = states.shape[0]
+    amb = relu_ambiguous(p, states, eps)
+    r = got_flat.astype(np.float64) - flatten_params(g_ref)
+    if not amb:
+        return unflatten_params(r), np.zeros(0), amb
+    cols = []
+    cache = {}
+    for s, layer, idx, _ in amb:
+        if s not in cache:      # one forward pass per sample; every flip of that sample is one more backward pass
+            sl = slice(s, s + 1)
+            mu, sigma, vs, c = conv_forward(p, states[sl], scale, keep=True)
+            _, _, _, dmu, dsigma, dvs = gaussian_loss_terms(mu, sigma, actions[sl], advantages[sl], critic_target[sl], vs, beta, scale)
+            m = {k: c[k] > 0 for k in RELU_LAYERS}
+            cache = {s: (mu, sigma, c, dmu, dsigma, dvs, m, flatten_params(_conv_backward(p, c, mu, sigma, dmu, dsigma, dvs, m, scale)))}
+        mu, sigma, c, dmu, dsigma, dvs, m, base = cache[s]
+        m[layer].reshape(-1)[idx] ^= True
+        cols.append((flatten_params(_conv_backward(p, c, mu, sigma, dmu, dsigma, dvs, m, scale)) - base) / N)
+        m[layer].reshape(-1)[idx] ^= True
+    A = np.stack(cols, axis=1)
+    keep = np.abs(A).max(axis=0) > 0          # an element without upstream gradient cannot be seen either way
+    coef = np.zeros(A.shape[1])
+    if keep.any():
+        # every block counts relative to its own largest entry (the blocks' scales differ by 10^4, and the comparison that follows is
+        # per block); normal equations: A is (2.2 M x k) with k ~ 100, its Gram matrix is small
+        w = flatten_params({n: np.full(np.shape(g_ref[n]), 1.0 / max(np.abs(g_ref[n]).max(), 1e-300)) for n, _ in CONV_PARAM_SHAPES})
+        Ak = A[:, keep] * w[:, None]
+        coef[keep] = np.linalg.lstsq(Ak.T @ Ak, Ak.T @ (r * w), rcond=1e-10)[0]
+    return unflatten_params(r - A @ coef), coef, amb
 
 
 def clip_by_global_norm(grads_flat, clip_norm):

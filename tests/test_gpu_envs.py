@@ -568,3 +568,68 @@ def test_flat_envs_full_size_properties():
         rew = full.read("reward").astype(np.float64)
         np.testing.assert_allclose(full.get_state("TRADE_ASSETS").reshape(-1)[alive], assets1[alive], rtol=2e-5)
         np.testing.assert_allclose(rew[alive], (np.log(assets1 + 1e-4) - np.log(assets_prev + 1e-4))[alive], rtol=0, atol=2e-4)
+
+
+# ------------------------------------------------------------------------------------------ env kwargs (round 4)
+def test_swarm_step_without_wind_golden(golden):
+    """SwarmEnv._step(v_action, add_wind=False) (multiagent.py:30-44) through grl_swarm_step_opts: the reference's own outputs for
+    float64 and float32 action rows, teacher-forced; agents bit-exact, locusts to 1e-12."""
+    g = golden("env_kwargs")
+    for f32 in (False, True):
+        m = g["nowind_f32"] == f32
+        E = int(m.sum())
+        eng = swarm_engine(E, max_episode_steps=0)
+        eng.set_state("SWARM_X", g["nowind_x"][m]); eng.set_state("SWARM_XA", g["nowind_xa"][m])
+        eng.set_state("SWARM_PNOISE", g["nowind_particle_noise"][m]); eng.set_state("SWARM_ANOISE", g["nowind_agent_noise"][m])
+        eng.swarm_step_opts(g["nowind_action"][m].astype(np.float32 if f32 else np.float64), add_wind=False)
+        assert np.array_equal(eng.get_state("SWARM_XA"), g["nowind_xa_out"][m])
+        np.testing.assert_allclose(eng.get_state("SWARM_X"), g["nowind_x_out"][m], rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(eng.read("reward_f64"), g["nowind_reward"][m], rtol=1e-12)
+        eng.close()
+    # the facade's keyword (goldsrl/envs/multiagent.py) reaches the same entry point
+    from goldsrl.envs.multiagent import SwarmEnv
+    env = SwarmEnv(seed=192)
+    env.reset()
+    env._eng.set_state("SWARM_X", g["nowind_x"][:1]); env._eng.set_state("SWARM_XA", g["nowind_xa"][:1])
+    env._eng.set_state("SWARM_PNOISE", g["nowind_particle_noise"][:1]); env._eng.set_state("SWARM_ANOISE", g["nowind_agent_noise"][:1])
+    (x, xa), r, d, info = env._step(g["nowind_action"][0], add_wind=False)
+    assert np.array_equal(xa, g["nowind_xa_out"][0]) and not d and info == {}
+    np.testing.assert_allclose(r, g["nowind_reward"][0], rtol=1e-12)
+
+
+def test_trade_starting_balance_std_p_n_assets_golden(golden):
+    """TradeAR1Env(starting_balance=25, n_assets=3, std_p=0.1) and the auto-reset of a depleted starting_balance=3 env
+    (fed_env.py:269-330) against the reference's own episode."""
+    g = golden("env_kwargs")
+    f = ffi()
+    n, sb, sp = int(g["tk_n"]), float(g["tk_starting_balance"]), float(g["tk_std_p"])
+    eng = trade_engine(1, n_assets=n, trade_std_p=sp, trade_starting_balance=sb, flags=f.F_INJECT_NOISE)
+    eng.reset()
+    np.testing.assert_allclose(eng.read("obs_raw")[0], g["tk_obs0"])
+    for t in range(len(g["tk_actions"])):
+        eng.set_state("TRADE_NORMALS", g["tk_normals"][t][None])
+        eng.step(g["tk_actions"][t][None].astype(np.float32))
+        np.testing.assert_allclose(eng.read("obs_raw")[0], g["tk_obs"][t], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(eng.read("reward")[0], g["tk_reward"][t], rtol=1e-5, atol=1e-9)
+        assert bool(eng.read("done")[0]) == bool(g["tk_done"][t])
+    eng.close()
+    eng = trade_engine(1, n_assets=2, trade_starting_balance=3.0, flags=f.F_INJECT_NOISE)
+    eng.reset()
+    np.testing.assert_allclose(eng.read("obs_raw")[0], g["td_obs0"])
+    for t in range(len(g["td_actions"])):
+        eng.set_state("TRADE_NORMALS", g["td_normals"][t][None])
+        eng.step(g["td_actions"][t][None].astype(np.float32))
+        assert bool(eng.read("done")[0]) == bool(g["td_done"][t])
+        np.testing.assert_allclose(eng.read("reward")[0], g["td_reward"][t], rtol=1e-5, atol=1e-9)
+        if not g["td_done"][t]:
+            np.testing.assert_allclose(eng.read("obs_raw")[0], g["td_obs"][t], rtol=1e-5, atol=1e-30)
+    np.testing.assert_allclose(eng.read("obs_raw")[0], g["td_reset_obs"])      # auto-reset: the starting balance again (quirk Q6)
+    np.testing.assert_allclose(eng.get_state("TRADE_CASH"), [3.0]); np.testing.assert_allclose(eng.get_state("TRADE_ASSETS"), [3.0])
+    eng.close()
+    # the facade's constructor arguments, and a starting balance the log cannot take
+    from goldsrl.envs.fed_env import TradeAR1Env
+    env = TradeAR1Env(starting_balance=sb, n_assets=n, std_p=sp)
+    np.testing.assert_allclose(env.reset(), g["tk_obs0"])
+    assert env.starting_balance == sb and env.std_e == float(g["tk_std_e"])
+    with pytest.raises(f.GrlError):
+        trade_engine(1, n_assets=2, trade_starting_balance=0.0)

@@ -281,6 +281,39 @@ def test_a_rollout_that_left_the_range_gives_its_update_up_and_the_next_one_is_v
     net.close()
 
 
+def test_an_update_whose_new_background_row_leaves_the_range_is_applied_exactly_once():
+    """train_apply() rebuilds the trunk's background rows from the UPDATED parameters with two fp16-form GEMMs before it reads the
+    range flag.  If those overflow, the flag says nothing about the gradient pass Adam has just applied: the update must stand,
+    applied once (Adam step count 1, moments of one step), and the net moves to the fp32 form for what follows -- it must not be
+    reported as GRL_E_RANGE and run a second time on the same rollout (round-3 advisor finding).  A learning rate of 300 makes the
+    first Adam step move every weight by ~300: the gradient pass itself is inside the range, the new background (conv2 of a constant
+    image of ~300s through weights of ~300) is far outside, and float32 still holds what the new net computes."""
+    E = 4
+    eng, net, p, states, obs = _setup(E)
+    flat0 = net.get_params().astype(np.float64)
+    act, adv, y = _train_inputs(E, seed=2)
+    lr = 300.0
+    _, _, _, g, _ = NN.conv_loss_and_grads(p, states, act.astype(np.float64), adv.astype(np.float64), y.astype(np.float64), 0.02, 1000.0)
+    gf, norm = NN.clip_by_global_norm(NN.flatten_params(g), 40.0)
+    pf, m1, v1 = NN.adam_step(flat0.copy(), gf, np.zeros_like(flat0), np.zeros_like(flat0), 1, lr)
+    st = net.train_obs(*obs, act, adv, y, lr=lr, apply_update=True)
+    assert np.isfinite(list(st.values())).all()
+    np.testing.assert_allclose(st["global_norm"], norm, rtol=2e-4)
+    opt = net.get_optimizer_state()
+    assert opt["adam_step"] == 1
+    assert net.range_info() == {"gemm_f32": True, "fallbacks": 1, "update_skipped": False}
+    got = net.get_params().astype(np.float64)
+    moved = np.abs(got - flat0)
+    big = np.abs(gf) > 1e-4 * np.abs(gf).max()      # where Adam's ratio g / (|g| + eps') is insensitive to float32 rounding of g
+    assert big.sum() > 1000 and moved.max() <= lr * 1.0001 and moved[big].min() > 0.99 * lr      # one step of ~lr, not two
+    np.testing.assert_allclose((got - flat0)[big], (pf - flat0)[big], rtol=2e-3)
+    np.testing.assert_allclose(opt["adam_m"][big], m1[big], rtol=2e-3, atol=0)
+    # the next call runs on the fp32 form with the new parameters (the heads saturate with weights of 300: finite is the check)
+    out = net.predict()
+    assert all(np.isfinite(out[k]).all() for k in out) and net.range_info()["fallbacks"] == 1
+    net.close()
+
+
 @pytest.mark.parametrize("A", [1, 3, 4])
 def test_num_actions_is_a_parameter_of_the_heads(A):
     """ConvSingleAgentPolicyNetwork takes conf['num_actions'] (policy_v_network.py:10,40-43; the reference's own shape test

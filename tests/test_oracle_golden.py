@@ -215,3 +215,36 @@ def test_episode_bookkeeping_restatement_on_a_hand_example():
     r = np.full((3, 1), np.float32(0.1))
     recs3, *_ = O.episode_bookkeeping(r, np.array([[0], [0], [1]], np.uint8))
     assert recs3[0][3] == float(np.float32(0.1)) * 3 or abs(recs3[0][3] - 3 * float(np.float32(0.1))) < 1e-15
+
+
+# ------------------------------------------------------------------------------------------ env kwargs (round 4)
+def test_swarm_step_without_wind_golden(golden):
+    """SwarmEnv._step(v_action, add_wind=False) (multiagent.py:30-44): float64 and float32 action rows, teacher-forced."""
+    g = golden("env_kwargs")
+    for f32 in (False, True):
+        m = g["nowind_f32"] == f32
+        act = g["nowind_action"][m].astype(np.float32 if f32 else np.float64)
+        x, xa, rew, done = O.swarm_step(g["nowind_x"][m], g["nowind_xa"][m], act, g["nowind_agent_noise"][m], g["nowind_particle_noise"][m],
+                                        add_wind=False)
+        assert np.array_equal(xa, g["nowind_xa_out"][m])
+        np.testing.assert_allclose(x, g["nowind_x_out"][m], rtol=1e-13, atol=1e-15)
+        np.testing.assert_allclose(rew, g["nowind_reward"][m], rtol=1e-13)
+        # and the wind does matter: the default step moves the agents elsewhere
+        _, xa_w, _, _ = O.swarm_step(g["nowind_x"][m], g["nowind_xa"][m], act, g["nowind_agent_noise"][m], g["nowind_particle_noise"][m])
+        assert np.abs(xa_w - xa).max() > 0.04
+
+
+def test_trade_starting_balance_std_p_n_assets_golden(golden):
+    """TradeAR1Env(starting_balance=25, n_assets=3, std_p=0.1) (fed_env.py:269-330)."""
+    g = golden("env_kwargs")
+    n, sb = int(g["tk_n"]), float(g["tk_starting_balance"])
+    std_e = O.trade_std_e(float(g["tk_std_p"]))
+    assert std_e == float(g["tk_std_e"])
+    assert np.array_equal(g["tk_obs0"], np.concatenate([[sb], np.zeros(n), np.ones(n)]))
+    cash, assets, q, p = np.array([sb]), np.array([sb]), np.zeros((1, n)), np.ones((1, n))
+    for t in range(len(g["tk_actions"])):
+        cash, assets, q, p, obs, rew, done = O.trade_step(cash, assets, q, p, g["tk_actions"][t][None], g["tk_normals"][t][None], std_e)
+        np.testing.assert_allclose(obs[0], g["tk_obs"][t], rtol=1e-13)
+        np.testing.assert_allclose(rew[0], g["tk_reward"][t], rtol=1e-10, atol=1e-15)
+        assert bool(done[0]) == bool(g["tk_done"][t])
+    assert np.array_equal(g["td_obs0"], [3.0, 0, 0, 1, 1]) and np.array_equal(g["td_reset_obs"], g["td_obs0"]) and g["td_done"][-1]
