@@ -73,6 +73,7 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the rollout_only / env_only side measurements")
     ap.add_argument("--cpu-sample-envs", type=int, default=2048)
     ap.add_argument("--no-strong", action="store_true", help="N>1: skip the strong-scaling point (32 768 envs in total)")
+    ap.add_argument("--no-legs", action="store_true", help="skip the dense_form / interior_policy legs (two more 32 768-env jobs)")
     ap.add_argument("--no-flat-configs", action="store_true", help="skip the Solow-4096 / TradeAR1-16 side blocks (configs 2 and 5)")
     ap.add_argument("--exchange", default="rccl", choices=["rccl", "host"],
                     help="gradient exchange for N>1: RCCL all-reduce inside the library (falls back together if any rank cannot "
@@ -260,6 +261,79 @@ def flat_config_block(kind, E, T, device_id, steps=10):
     return out
 
 
+def inject_interior_agents(eng, rng):
+    """Put every agent into the interior of its env's observation box (the place a trained policy takes them: near the swarm) and
+    refresh the observation.  The box is x in [mean_x - 1.5, mean_x + 1.5], y in [0, 6] over 84 bins (state_processors.py:17-27);
+    agents go to x = mean_x(locusts) + U(-1.2, 0), y = U(1.5, 4.3): bins ~8..42 in x (the wind carries them ~28 bins to the right
+    over a 20-step rollout, multiagent.py:35-36) and 21..60 in y.  Returns the share of agents whose bins are all inside 8..75."""
+    x = eng.get_state("SWARM_X")
+    E = x.shape[0]
+    mean_x = x[:, :, 0].mean(axis=1)
+    xa = np.empty((E, 10, 2))
+    xa[:, :, 0] = mean_x[:, None] + rng.uniform(-1.2, 0.0, size=(E, 10))
+    xa[:, :, 1] = rng.uniform(1.5, 4.3, size=(E, 10))
+    eng.set_state("SWARM_XA", xa)
+    eng.observe()
+    eng.wait()
+    pos = eng.read("positions").astype(int)
+    return float(((pos >= 8) & (pos <= 75)).all(axis=2).mean())
+
+
+def workload_leg(args, ranks, E, T, env=None, interior=False, steps=3):
+    """The same full PAAC update as `value`, on one more form of the evaluation (env: GRL_* switches read when the net is created) or
+    one more state distribution (interior: agents re-injected into the interior of the box before every update, outside the timed
+    region): ms per update, env-steps/s, and -- from a single-stream pass with HIP events around every GEMM -- the executed share
+    of SURVEY 8(d)'s contract FLOPs and of the dense1 5x5 patch."""
+    from goldsrl import _ffi
+    from goldsrl import rollout as R
+    saved = {k: os.environ.get(k) for k in (env or {})}
+    os.environ.update(env or {})
+    device = int(os.environ["GRL_BENCH_FORCE_DEVICE"]) if "GRL_BENCH_FORCE_DEVICE" in os.environ else ranks.local_rank
+    eng = _ffi.Engine(_ffi.ENV_SWARM, E, device_id=device, seed=1692)
+    eng.reset()
+    roll = R.ConvPolicyRollout(eng, T, train=True)
+    for k, v in saved.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+    rng = np.random.RandomState(4)
+    shares = []
+
+    def prepare():
+        if interior:
+            shares.append(inject_interior_agents(eng, rng))
+    prepare()
+    roll.run(); eng.wait()
+    per = []
+    for _ in range(steps):
+        prepare()
+        t0 = time.perf_counter()
+        roll.run(); eng.wait()
+        per.append(time.perf_counter() - t0)
+    prepare()
+    roll.net.profile_enable(True)
+    roll.run(); eng.wait()
+    launches, ms, flops = roll.net.profile_read()
+    tags = roll.net.profile_read_tags()
+    roll.net.profile_enable(False)
+    dt = sum(per) / len(per)
+    contract = 18.10e6 * 10 * E * ((T + 1) + 3 * T)
+    chunk_samples = min(E * 10, 81920)
+    patch = {}
+    for fam in ("dense1_patch_fwd", "dense1_patch_dgrad", "dense1_patch_wgrad"):
+        if fam in tags and tags[fam][0] > 0:
+            patch[fam] = tags[fam][2] / (tags[fam][0] * 2.0 * chunk_samples * 1600 * 512)
+    out = {"ms_per_update": dt * 1e3, "ms_per_update_spread": spread(per), "value": E * T / dt, "unit": "env-steps/s", "steps": steps,
+           "executed_share": flops / contract, "executed_tflop_per_update": flops / 1e12,
+           "patch_support_share": patch, "gemm_ms_single_stream": ms, "gemm_tflops": flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
+           "gemm_frac": (flops / (ms * 1e-3) / 1e12 / MFMA_X3_PEAK_TFLOPS) if ms > 0 else 0.0}
+    if interior:
+        out["agents_inside_bins_8_75"] = sum(shares) / len(shares)
+    roll.net.close(); eng.close()
+    return out
+
+
 def measure_swarm(args, ranks, E, T, want_roofline, label):
     """One Swarm PAAC workload on this rank's shard of E envs: warmup, K timed updates (barrier + device sync on both sides,
     max over ranks), then (rank 0, single-stream extra update) the per-GEMM HIP-event pass for the roofline."""
@@ -287,9 +361,21 @@ def measure_swarm(args, ranks, E, T, want_roofline, label):
     for _ in range(args.warmup):
         roll.run()
     barrier()
+    ht0 = net.host_times() if net is not None else None
     elapsed, per_update = timed_each(roll.run, eng.wait, args.steps)
+    ht1 = net.host_times() if net is not None else None
     ranks.barrier()
     elapsed = ranks.max(elapsed)
+    host = None
+    if ht0 is not None and ht1["updates"] > ht0["updates"]:
+        # what the host thread of THIS rank did per update: ms inside grl_net_rollout (asynchronous: all enqueue work) and inside
+        # grl_net_train_rollout up to its final stream synchronisation, and ms waiting in that synchronisation
+        k = float(ht1["updates"] - ht0["updates"])
+        mine = {"rank": rank, "rollout_enqueue_ms": (ht1["rollout_enqueue_ms"] - ht0["rollout_enqueue_ms"]) / k,
+                "train_enqueue_ms": (ht1["train_enqueue_ms"] - ht0["train_enqueue_ms"]) / k,
+                "train_wait_ms": (ht1["train_wait_ms"] - ht0["train_wait_ms"]) / k}
+        mine["host_enqueue_ms_per_update"] = mine["rollout_enqueue_ms"] + mine["train_enqueue_ms"]
+        host = [json.loads(x.decode()) for x in ranks.allgather_bytes(json.dumps(mine).encode())]
     # env step kernel alone (roofline_env_step): in the conv rollout every chunk's step overlaps other chunks' kernels and has no
     # clean duration, so it is timed here on whole-batch launches of a short random-policy rollout (HIP events on the handle's stream)
     probe = RandomPolicyRollout(eng, 4) if args.policy == "conv" else roll
@@ -310,7 +396,7 @@ def measure_swarm(args, ranks, E, T, want_roofline, label):
                 "allreduce_ms": [r["allreduce_ms"] for r in per_rank],
                 "params_equal_across_ranks": bool(D.params_equal_across_ranks(net, ranks))}
     res = {"eng": eng, "roll": roll, "net": net, "exchange": exchange, "elapsed": elapsed, "E": E, "per_update": per_update,
-           "comm": comm,
+           "comm": comm, "host": host,
            "env_launches": env_launches, "env_kernel_ms": env_kernel_ms, "gemm": None, "gemm_step_s": None, "gemm_tags": {}}
     # GEMM roofline: one more update of the same workload with a HIP event pair around every gemm_rowk / gemm_tn launch.
     # Per-launch events need the launches serialised, so this pass runs on one stream; the timed region above alternates
@@ -341,6 +427,12 @@ def main():
             sys.stderr.write("bench.py: a rank failed (exit code %d); no result line\n" % rc)
         sys.exit(rc)
 
+    # One process per GPU: keep this rank's host thread (and every thread the HIP runtime / RCCL start later) on the cores of its
+    # GPU's NUMA node.  Found in sysfs, applied BEFORE anything touches the GPU (goldsrl/affinity.py); reported in the line.
+    from goldsrl import affinity
+    local = int(os.environ.get("GRL_BENCH_FORCE_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    pin = affinity.pin_to_gpu(local)
+
     from goldsrl import distributed as D
     ranks = D.Ranks()
     if ranks.world != args.gpus:
@@ -350,6 +442,7 @@ def main():
     E, T = args.envs, args.T
 
     m = measure_swarm(args, ranks, E, T, want_roofline=True, label="weak")
+    m["pin"] = [json.loads(x.decode()) for x in ranks.allgather_bytes(json.dumps(pin).encode())]
     eng, roll, net, exchange, elapsed = m["eng"], m["roll"], m["net"], m["exchange"], m["elapsed"]
     env_launches, env_kernel_ms, gemm, gemm_step_s, gemm_tags = m["env_launches"], m["env_kernel_ms"], m["gemm"], m["gemm_step_s"], m["gemm_tags"]
 
@@ -386,6 +479,17 @@ def main():
         if sm["net"] is not None:
             sm["net"].close()
         sm["eng"].close()
+    if world == 1 and not args.no_extras and not args.no_legs and args.policy == "conv" and not args.no_train and not args.single_stream:
+        # how much of `value` is the workload: the same update (a) without the zero-skipping forms, (b) with agents in the interior
+        extras["dense_form"] = workload_leg(args, ranks, E, T, env={"GRL_PATCH_SKIP": "off", "GRL_TRUNK_SKIP": "off"})
+        extras["dense_form"]["what"] = ("the same update with GRL_PATCH_SKIP=off GRL_TRUNK_SKIP=off: plain 5x5 dense1 patches, all 9 conv3 taps of "
+                                        "every slot, the env-level trunk over every pixel (no row lists, no background terms, no union mask)")
+        extras["interior_policy"] = workload_leg(args, ranks, E, T, interior=True)
+        extras["interior_policy"]["what"] = ("the same update (default zero-skipping forms) on a state distribution with the agents INSIDE the "
+                                             "observation box -- positions injected before every update, outside the timed region: x = "
+                                             "mean_x + U(-1.2, 0), y = U(1.5, 4.3) -- where an agent's conv3 footprint is ~75 % of its 5x5 "
+                                             "patch instead of ~25 % at the rim; `value` above stays on SURVEY 8(d)'s prescribed workload "
+                                             "(random-init policy from the env's own reset states)")
     if world == 1 and not args.no_flat_configs and not args.no_extras and args.policy == "conv":
         device = int(os.environ.get("GRL_BENCH_FORCE_DEVICE", ranks.local_rank))
         extras["solow_4096"] = flat_config_block("solow", 4096, T, device)
@@ -433,6 +537,16 @@ def main():
                        "streams": 1 if (args.single_stream or args.policy != "conv") else 4,
                        "gradient_exchange": exchange},
         }
+        out["config"]["cpu_affinity"] = m["pin"][0] if world == 1 else m["pin"]
+        if m["host"] is not None:
+            # max over ranks: the slowest host thread is what a lock-step job waits for
+            out["host_enqueue_ms_per_update"] = max(h["host_enqueue_ms_per_update"] for h in m["host"])
+            out["host"] = {"per_rank": m["host"],
+                           "note": "wall-clock ms of the rank's host thread inside grl_net_rollout (asynchronous) + inside "
+                                   "grl_net_train_rollout before its final stream synchronisation, per update; train_wait_ms = inside "
+                                   "that synchronisation.  Enqueue calls block when a stream's launch queue is full, so enqueue ~ "
+                                   "ms_per_step means 'the host keeps the queues full', not 'the host is the bottleneck': the "
+                                   "host-bound signature is train_wait_ms ~ 0"}
         if m["comm"] is not None:
             out["rccl_ranks"] = m["comm"]["rccl_ranks"]
             out["gradient_exchange"] = exchange

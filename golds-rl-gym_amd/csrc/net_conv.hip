@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <cmath>
 #include <string>
 #include <vector>
@@ -179,6 +180,10 @@ struct grl_net : NetLane {
     hipEvent_t ar_ev0, ar_ev1; // bracket the all-reduce on the handle's stream (grl_net_comm_info)
     int ar_pending;
     long ar_calls;
+    // host clocks of the actor loop (grl_net_host_times)
+    long ht_rollouts, ht_updates;
+    double ht_rollout_ms, ht_train_enq_ms, ht_train_wait_ms;
+    double ht_train_t0;      // steady-clock ms at the entry of the gradient step in flight (0: none)
     double ar_ms_total;
     float ar_ms_last;
     // Rollout-resident activations: the rollout's forward pass writes its activations of every (step, chunk) into one
@@ -865,7 +870,7 @@ int grl_net_create(grl_handle *h, const grl_net_config *cfg, grl_net **out) {
     n->ro_lb = nullptr; n->slab_floats = 0; n->w3t = n->w2t = nullptr;
     n->mu = n->sigma = n->vs = nullptr;
     n->keep_level = 0;
-    n->ar_ev0 = n->ar_ev1 = nullptr; n->ar_pending = 0; n->ar_calls = 0; n->ar_ms_total = 0.0; n->ar_ms_last = 0.f;
+    n->ar_ev0 = n->ar_ev1 = nullptr; n->ar_pending = 0; n->ar_calls = 0; n->ht_rollouts = n->ht_updates = 0; n->ht_rollout_ms = n->ht_train_enq_ms = n->ht_train_wait_ms = 0.0; n->ht_train_t0 = 0.0; n->ar_ms_total = 0.0; n->ar_ms_last = 0.f;
     n->keep = nullptr; n->keep_slots = 0; n->param_version = 0; n->keep_version = -1;
     n->shared_trunk = (cfg->reserved & GRL_NET_F_PER_AGENT_TRUNK) ? 0 : 1;     // the plain per-agent evaluation is the A/B reference
     n->cur_lane = 0; n->last_lane = 0;

@@ -44,6 +44,7 @@ NET_SIGNATURES = {
     "grl_net_comm_destroy": (C.c_int, [_P]),
     "grl_net_comm_info": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "grl_net_range_info": (C.c_int, [_P, _P, _P, _P]),
+    "grl_net_host_times": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "grl_net_set_gemm_f32": (C.c_int, [_P, C.c_int32]),
     "grl_net_profile_enable": (C.c_int, [_P, _I]),
     "grl_net_profile_read": (C.c_int, [_P, C.POINTER(_I), C.POINTER(C.c_float), C.POINTER(C.c_double)]),
@@ -257,6 +258,14 @@ class ConvNet(object):
 
     def comm_destroy(self):
         self._check(self.lib.grl_net_comm_destroy(self.n))
+
+    def host_times(self):
+        """Wall-clock ms this thread spent enqueueing rollouts / gradient steps and waiting for the device (grl_net_host_times)."""
+        ro, up = C.c_int64(0), C.c_int64(0)
+        a, b, c = C.c_double(0), C.c_double(0), C.c_double(0)
+        self._check(self.lib.grl_net_host_times(self.n, C.byref(ro), C.byref(up), C.byref(a), C.byref(b), C.byref(c)))
+        return {"rollouts": int(ro.value), "updates": int(up.value), "rollout_enqueue_ms": a.value, "train_enqueue_ms": b.value,
+                "train_wait_ms": c.value}
 
     def range_info(self):
         """Arithmetic form of the GEMMs: 'gemm_f32' once a range violation (or set_gemm_f32) moved the net to the fp32 form,

@@ -54,6 +54,9 @@ class PAACLearner(ActorLearner):
         global ids rank*emulator_counts.. (the np.split of runners.py:18-19 across GPUs instead of worker processes)."""
         if getattr(self, "ranks", None) is None:
             self.ranks = D.Ranks().init()
+            if self.ranks.world > 1:      # before the engine's first HIP call: the runtime's threads inherit the mask (goldsrl/affinity.py)
+                from ... import affinity
+                self.cpu_affinity = affinity.pin_to_gpu(self.ranks.local_rank)
         return self.ranks
 
     def _loop(self, net, ranks, do_rollout, max_updates, between_updates=None):

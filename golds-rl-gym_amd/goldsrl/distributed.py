@@ -53,9 +53,27 @@ def _recv(sock):
     return _recv_exact(sock, n)
 
 
+def _rendezvous_dir():
+    """A directory only this user can write: <tmp>/goldsrl-<uid>, mode 0700, owned by us and not a symlink -- the port file is read
+    by every rank, so nobody else must be able to plant one."""
+    d = os.path.join(tempfile.gettempdir(), "goldsrl-%d" % os.getuid())
+    try:
+        os.mkdir(d, 0o700)
+    except FileExistsError:
+        pass
+    st = os.lstat(d)
+    import stat
+    if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+        raise RuntimeError("rendezvous: %s is not a private directory of this user (mode %o, uid %d)" % (d, st.st_mode & 0o777, st.st_uid))
+    return d
+
+
 def _rendezvous_file(env):
     key = "%s_%s" % (env.get("MASTER_PORT", "29500"), env.get("GRL_RDZV_KEY", str(os.getppid())))
-    return os.path.join(tempfile.gettempdir(), "goldsrl_rdzv_%s" % key)
+    return os.path.join(_rendezvous_dir(), "rdzv_%s" % key)
+
+
+_HELLO, _ACK = b"goldsrl-rank", b"goldsrl-store"
 
 
 class Ranks(object):
@@ -85,12 +103,24 @@ class Ranks(object):
             ls.bind((addr, int(fixed) if fixed else 0))
             ls.listen(self.world)
             self._listener = ls
+            # the job's nonce: every peer must present it and gets it echoed, so a peer that read a stale file (a crashed job's) and
+            # reached somebody else's listener rejects it and keeps polling, and rank 0 drops connections that are not its peers'
+            nonce = self.env.get("GRL_RDZV_KEY", "") if fixed else "%s-%s" % (self.env.get("GRL_RDZV_KEY", ""), os.urandom(8).hex())
             if not fixed:
                 self._file = _rendezvous_file(self.env)
+                try:
+                    os.unlink(self._file)            # a file left by a crashed job with the same key
+                except FileNotFoundError:
+                    pass
                 tmp = "%s.%d" % (self._file, os.getpid())
-                with open(tmp, "w") as f:
-                    f.write("%d\n" % ls.getsockname()[1])
-                os.replace(tmp, self._file)          # atomic: a reader sees the whole port or no file
+                try:
+                    os.unlink(tmp)
+                except FileNotFoundError:
+                    pass
+                fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, "O_NOFOLLOW", 0), 0o600)
+                with os.fdopen(fd, "w") as f:
+                    f.write("%d %s\n" % (ls.getsockname()[1], nonce))
+                os.replace(tmp, self._file)          # atomic: a reader sees the whole line or no file
             peers = [None] * (self.world - 1)
             ls.settimeout(1.0)
             while any(p is None for p in peers):
@@ -101,11 +131,22 @@ class Ranks(object):
                 except socket.timeout:
                     continue
                 c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                c.settimeout(timeout_s)
-                r = struct.unpack("<i", _recv(c))[0]
+                c.settimeout(5.0)
+                try:
+                    hello = _recv(c)
+                except (OSError, ConnectionError):
+                    c.close()
+                    continue
+                want = _HELLO + nonce.encode()
+                if len(hello) != len(want) + 4 or hello[:len(want)] != want:
+                    c.close()                        # not a rank of this job (port scanner, a peer of another job): ignore it
+                    continue
+                r = struct.unpack("<i", hello[len(want):])[0]
                 if not (1 <= r < self.world) or peers[r - 1] is not None:
                     c.close()
                     raise RuntimeError("rendezvous: unexpected rank %d" % r)
+                _send(c, _ACK + nonce.encode())
+                c.settimeout(timeout_s)
                 peers[r - 1] = c
             self._peers = peers
         else:
@@ -113,20 +154,27 @@ class Ranks(object):
             while True:
                 if time.time() > deadline:
                     raise TimeoutError("rendezvous: rank %d could not reach rank 0 (%s)" % (self.rank, last))
+                s = None
                 try:
                     if fixed:
-                        port = int(fixed)
+                        port, nonce = int(fixed), self.env.get("GRL_RDZV_KEY", "")
                     else:
                         with open(_rendezvous_file(self.env)) as f:
-                            port = int(f.read().strip())
+                            port, _, nonce = f.read().strip().partition(" ")
+                        port = int(port)
                     s = socket.create_connection((addr, port), timeout=5.0)
+                    s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    s.settimeout(5.0)
+                    _send(s, _HELLO + nonce.encode() + struct.pack("<i", self.rank))
+                    if _recv(s) != _ACK + nonce.encode():
+                        raise ConnectionError("the listener on port %d is not this job's rank 0" % port)
                     break
-                except (OSError, ValueError) as e:       # file not there yet, stale port, rank 0 not listening yet
+                except (OSError, ValueError, ConnectionError) as e:   # file not there yet, stale port, rank 0 not listening yet, foreign listener
                     last = e
+                    if s is not None:
+                        s.close()
                     time.sleep(0.05)
-            s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
             s.settimeout(timeout_s)
-            _send(s, struct.pack("<i", self.rank))
             self._sock = s
         self.barrier()
         return self

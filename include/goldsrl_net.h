@@ -147,6 +147,16 @@ int grl_net_set_gemm_f32(grl_net *net, int32_t on);
 int grl_net_comm_info(grl_net *net, int32_t *count_out, int32_t *user_rank_out, int64_t *allreduce_calls_out,
                       double *allreduce_ms_total_out, float *allreduce_ms_last_out);
 
+/* Host-side cost of the actor loop (the reference's learner thread spends its time in Python between session.run calls,
+ * paac.py:302-387; here the host only enqueues): wall-clock ms this thread spent inside grl_net_rollout (asynchronous: all of it is
+ * enqueue work) and inside grl_net_train_rollout* split at its first blocking call -- `train_enqueue` up to the stream
+ * synchronisation that ends the update, `train_wait` inside it -- summed over `updates_out` gradient steps since the net was created.
+ * With one rank per GPU and eight ranks per host this is the number that says whether a rank is bound by its host thread
+ * (enqueue ~ the whole update) or by its GPU (enqueue << update).  When the launch queues fill up, enqueue calls block on the
+ * device and the figure is an upper bound of the host's own work.  Any out pointer may be NULL. */
+int grl_net_host_times(grl_net *net, int64_t *rollouts_out, int64_t *updates_out, double *rollout_enqueue_ms_out,
+                       double *train_enqueue_ms_out, double *train_wait_ms_out);
+
 /* Per-kernel timing of the GEMM kernels for bench.py's roofline (HIP events around every launch
  * of gemm_rowk / gemm_tn while enabled): returns launches, summed ms and summed FLOPs. */
 int grl_net_profile_enable(grl_net *net, int32_t on);

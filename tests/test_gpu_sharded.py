@@ -206,3 +206,7 @@ def test_bench_under_the_elastic_launcher_two_ranks_on_one_gpu():
     else:
         assert j["rccl_ranks"] == 0
     assert "ms_per_step_spread" in j and j["ms_per_step_spread"]["n"] == 2
+    # what a rank's host thread costs per update, and where the rank was pinned (goldsrl/affinity.py) -- per rank in the line
+    assert j["host_enqueue_ms_per_update"] > 0 and len(j["host"]["per_rank"]) == 2
+    assert all(h["host_enqueue_ms_per_update"] > 0 and h["train_wait_ms"] >= 0 for h in j["host"]["per_rank"])
+    assert len(j["config"]["cpu_affinity"]) == 2 and all("pinned" in a for a in j["config"]["cpu_affinity"])

@@ -224,3 +224,58 @@ def test_host_exchange_update_is_taken_or_left_by_every_rank_together(tmp_path):
         "r.close()\n" % (os.path.join(ROOT, "golds-rl-gym_amd"), str(tmp_path)))
     assert D.spawn_local_ranks([sys.executable, str(child)], 2) == 0
     assert sorted(p.name for p in tmp_path.iterdir() if p.name.startswith("ok")) == ["ok0", "ok1"]
+
+
+def test_a_stale_rendezvous_file_pointing_at_a_foreign_listener_is_rejected(tmp_path):
+    """A crashed job can leave its port file behind and the port may since belong to somebody else (round-3 advisor finding): rank 1
+    reads the stale file first, reaches a listener that does not answer with this job's nonce, drops it and keeps polling; rank 0
+    removes the stale file, publishes its own port + nonce, and the two meet.  The file lives in a 0700 directory of this user."""
+    import socket
+    import stat
+    import threading
+    from goldsrl import distributed as D
+    key = "stale-test-%d" % os.getpid()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); mport = s.getsockname()[1]; s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(mport), GRL_RDZV_KEY=key, WORLD_SIZE="2")
+    env.pop("GRL_STORE_PORT", None)
+    # the foreign listener: accepts, reads, answers garbage
+    foreign = socket.socket(); foreign.bind(("127.0.0.1", 0)); foreign.listen(4); foreign.settimeout(0.2)
+    hits, stop = [], threading.Event()
+
+    def serve():
+        while not stop.is_set():
+            try:
+                c, _ = foreign.accept()
+            except socket.timeout:
+                continue
+            hits.append(1)
+            try:
+                c.settimeout(1.0); c.recv(64); c.sendall(b"\x05\x00\x00\x00\x00\x00\x00\x00hello")
+            except OSError:
+                pass
+            c.close()
+    th = threading.Thread(target=serve, daemon=True); th.start()
+    path = D._rendezvous_file(env)
+    d = os.path.dirname(path)
+    st = os.lstat(d)
+    assert stat.S_ISDIR(st.st_mode) and (st.st_mode & 0o077) == 0 and st.st_uid == os.getuid()
+    with open(path, "w") as f:
+        f.write("%d old-nonce\n" % foreign.getsockname()[1])
+    out = {}
+
+    def rank(r):
+        rk = D.Ranks(dict(env, RANK=str(r), LOCAL_RANK=str(r)))
+        if r == 0:
+            time.sleep(1.0)      # rank 1 meets the stale file first
+        rk.init(timeout_s=60)
+        out[r] = rk.sum(1.0 + r)
+        rk.close()
+    ts = [threading.Thread(target=rank, args=(r,)) for r in (0, 1)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(90)
+    stop.set(); th.join(2); foreign.close()
+    assert out == {0: 3.0, 1: 3.0}
+    assert hits, "rank 1 never tried the stale port (the test did not exercise the rejection)"
+    assert not os.path.exists(path)      # rank 0 removes its file on close
