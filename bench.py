@@ -441,6 +441,13 @@ def main():
     rank, world = ranks.rank, ranks.world
     E, T = args.envs, args.T
 
+    if not pin["pinned"] and "GRL_PIN_CPUS" not in pin.get("reason", ""):
+        # the KFD topology is not readable here (containers hide its GPU nodes): ask the runtime for the PCI address instead; the
+        # runtime's threads exist by then, so only this (the enqueuing) thread moves
+        from goldsrl import _ffi
+        pin2 = affinity.pin_to_pci(_ffi.device_pci_address(local))
+        pin2["sysfs_attempt"] = pin.get("reason")
+        pin = pin2
     m = measure_swarm(args, ranks, E, T, want_roofline=True, label="weak")
     m["pin"] = [json.loads(x.decode()) for x in ranks.allgather_bytes(json.dumps(pin).encode())]
     eng, roll, net, exchange, elapsed = m["eng"], m["roll"], m["net"], m["exchange"], m["elapsed"]

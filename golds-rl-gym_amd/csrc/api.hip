@@ -418,6 +418,16 @@ int grl_swarm_step_opts(grl_handle *h, const void *actions_host, int32_t actions
     return rc;
 }
 
+int grl_device_pci_address(int32_t device_id, char *out, size_t bytes) {
+    if (!out || bytes < 16) return GRL_E_INVALID;
+    char buf[64] = {0};
+    if (hipDeviceGetPCIBusId(buf, (int)sizeof(buf), device_id) != hipSuccess) { (void)hipGetLastError(); return GRL_E_HIP; }
+    for (char *c = buf; *c; ++c) if (*c >= 'A' && *c <= 'F') *c = (char)(*c - 'A' + 'a');      // sysfs spells addresses in lower case
+    strncpy(out, buf, bytes - 1);
+    out[bytes - 1] = 0;
+    return GRL_OK;
+}
+
 int grl_wait(grl_handle *h) {
     if (!h) return GRL_E_INVALID;
     hipSetDevice(h->cfg.device_id);

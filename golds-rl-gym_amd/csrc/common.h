@@ -119,7 +119,7 @@ int episodes_launch_account(grl_handle *h, int env_base = 0, int count = -1);
 // swarm.hip
 int swarm_alloc(grl_handle *h);
 int swarm_launch_step(grl_handle *h, const float *actions_dev, const double *actions64_dev = nullptr, int no_wind = 0);
-int swarm_launch_step_range(grl_handle *h, const float *actions_dev, int env_base, int count, int slot);
+int swarm_launch_step_range(grl_handle *h, const float *actions_dev, int env_base, int count, int slot, bool counter_zeroed = false);
 int swarm_launch_reset(grl_handle *h, const int32_t *list_dev, const int32_t *count_dev, int max_count);
 int swarm_launch_observe(grl_handle *h);
 int swarm_reset_injected(grl_handle *h, const double *x0, const double *xa0, const double *ra,

@@ -19,6 +19,7 @@
 #include "../../include/goldsrl_net.h"
 #include "common.h"
 #include "net_gemm.h"
+#include "net_reduce.inc"
 #include "rng.h"
 
 namespace grl {
@@ -138,6 +139,7 @@ struct grl_net : NetLane {
     long adam_t;
     float *w3t, *w2t;          // rearranged conv weights for the data gradients
     float *w3f;                // w3f[(tap,co)][ci] = W3[tap][ci][co] (slot product GEMM of conv3's forward)
+    float *wpvT;               // [pol1_w | v1_w] transposed side by side: (1024, 256), the B operand of the one GEMM that computes both from d2
     int shared_trunk;
     // GEMM arithmetic: 0 = three fp16 products (operands must stay inside the fp16 range), 1 = v_mfma_f32_16x16x4_f32 (no range
     // limit, 103 instead of 200 TFLOP/s).  A pass that raised the range flag switches the net to 1 (range_fallback below).
@@ -156,7 +158,9 @@ struct grl_net : NetLane {
     grl::HeadOff ho;           // offsets of the head / value parameters for this net's num_actions
     int npad, ptiles, pslices, pslice_rows, pwgrad_xcd, pdgrad_xcd;
     int tn_wgs, tn_wgs_dense;  // workgroups a split-M weight-gradient launch aims at (slab count = tn_wgs / tiles)      // dense1 patch weight gradient: slice length and tile order (tuning knobs)
-    size_t slab_floats;
+    size_t slab_floats, slab_used, slabb_floats, slabb_used;      // bump allocation of a chunk's partial-sum regions (net_train.inc)
+    std::vector<grl::RJob> rq;      // the chunk's queued reductions (net_reduce.inc)
+    std::vector<int> rq_dst;
     float *stats;              // device: [0..4] loss parts / norm / clip factor, [8..9] loss scale S and 1/S, [10] bits of the head-gradient bound
     // rollout storage (allocated by grl_net_rollout)
     int T, B;
@@ -335,9 +339,12 @@ static void refresh_transposes(grl_net *net) {
     const struct { long off; int K, N; } L[] = {
         {ConvOffsets::c2w, 512, 64}, {ConvOffsets::c3w, 576, 64}, {ConvOffsets::d1w, 3136, 512}, {ConvOffsets::d2w, 512, 256},
         {ConvOffsets::p1w, 256, 512}, {net->ho.v1w, 256, 512}, {net->ho.v2w, 512, 256}};
-    for (const auto &l : L)
+    for (const auto &l : L) {
+        // pol1 and v1 run as ONE N = 1024 GEMM on d2 (forward_chunk): their transposed kernels sit side by side in wpvT
+        float *dst = l.off == ConvOffsets::p1w ? net->wpvT : l.off == net->ho.v1w ? net->wpvT + (size_t)512 * 256 : net->paramsT + l.off;
         hipLaunchKernelGGL(transpose_kernel, dim3((l.N + 31) / 32, (l.K + 31) / 32), dim3(32, 8), 0, net->h->stream, net->params + l.off,
-                           l.K, l.N, net->paramsT + l.off);
+                           l.K, l.N, dst);
+    }
     hipLaunchKernelGGL(conv2_corr_weights_kernel, dim3((4 * 576 * 128 + 255) / 256), dim3(256), 0, net->h->stream, net->params + ConvOffsets::c2w,
                        net->w2corr);
     for (int tap = 0; tap < 9; ++tap)     // w3f[(tap, co)][ci]: each tap's 64x64 block transposed
@@ -594,9 +601,24 @@ __global__ __launch_bounds__(256) void heads_forward_kernel(const float *__restr
     }
 
 // a = mu + sigma * N(0,1) (paac.py:418), then SwarmRunner.transform_actions_for_env (emulator_runner.py:113-118)
+// The same launch keeps the compact observation the action was chosen from -- states[t] = shared_states (paac.py:319): 200 bytes per
+// env, copied word by word from the handle's observation (obs_src: lbins / abins / pos of the chunk's first env) into the rollout's
+// step t -- and zeroes the done counter the env step that follows on this stream appends to (three copies and a memset until round 3).
+struct ObsRecord {
+    const uint32_t *lb, *ab, *pos;      // sources, already at the chunk's first env
+    uint32_t *ro_lb, *ro_ab, *ro_pos;   // destinations, already at (step, first env)
+    int nenv;
+    int32_t *done_count;
+};
 __global__ void sample_actions_kernel(const float *__restrict__ mu, const float *__restrict__ sigma, int i0, int n, uint64_t seed,
-                                      uint32_t env_off, uint32_t counter, float *__restrict__ raw, float *__restrict__ envact) {
+                                      uint32_t env_off, uint32_t counter, float *__restrict__ raw, float *__restrict__ envact, ObsRecord R) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;      // samples [i0, i0 + n) of the batch
+    if (R.done_count && i == 0) *R.done_count = 0;
+    for (int w = i; w < R.nenv * 50; w += gridDim.x * blockDim.x) {      // 40 + 5 + 5 words per env
+        if (w < R.nenv * 40) R.ro_lb[w] = R.lb[w];
+        else if (w < R.nenv * 45) R.ro_ab[w - R.nenv * 40] = R.ab[w - R.nenv * 40];
+        else R.ro_pos[w - R.nenv * 45] = R.pos[w - R.nenv * 45];
+    }
     if (i >= n) return;
     i += i0;
     int env = i / 10, a = i - env * 10;
@@ -710,8 +732,12 @@ static int forward_chunk(grl_net *net, const uint8_t *lb, const uint8_t *ab, con
     };
     if (!net->shared_trunk) dense(net->a3, 3136, PT + ConvOffsets::d1w, P + ConvOffsets::d1b, 512, net->d1, nullptr);
     dense(net->d1, 512, PT + ConvOffsets::d2w, P + ConvOffsets::d2b, 256, net->d2, net->mb_d2);
-    dense(net->d2, 256, PT + ConvOffsets::p1w, P + ConvOffsets::p1b, 512, net->p1, nullptr);
-    dense(net->d2, 256, PT + net->ho.v1w, P + net->ho.v1b, 512, net->v1, net->mb_v1);
+    {   // pol1 and v1 in one launch: N = 1024 over [pol1_w | v1_w] (A tile d2 staged once, one launch less per forward pass)
+        DenseRows g{net->d2, n, 256, 256};
+        GemmTimer t(net, 2.0 * n * 256 * 1024);
+        EpiBiasActSplit e{net->p1, net->v1, 512, 512, P + ConvOffsets::p1b, P + net->ho.v1b, net->mb_v1, 8};
+        launch_rowk<128, 128, kW128M, kW128N, DenseRows, EpiBiasActSplit>(net, dim3(1024 / 128, (n + 127) / 128), st, g, net->wpvT, 256, 1024, e);
+    }
     dense(net->v1, 512, PT + net->ho.v2w, P + net->ho.v2b, 256, net->v2, nullptr);
     }
     if (!skip_heads)      // (the gradient step over a resident rollout has the heads' outputs of every step already)
@@ -867,7 +893,7 @@ int grl_net_create(grl_handle *h, const grl_net_config *cfg, grl_net **out) {
     n->h = h; n->cfg = *cfg; n->chunk = cfg->max_chunk_samples; n->adam_t = 0;
     n->ho = head_offsets(cfg->num_actions);
     n->T = 0; n->B = 0; n->tmp_envs = 0; n->act_counter = 0; n->prof_on = false; n->prof_used = 0; n->prof_flops = 0; n->last_n = 0; n->prof_tag_cur = 0;
-    n->ro_lb = nullptr; n->slab_floats = 0; n->w3t = n->w2t = nullptr;
+    n->ro_lb = nullptr; n->slab_floats = 0; n->slab_used = 0; n->slabb_floats = 0; n->slabb_used = 0; n->w3t = n->w2t = nullptr;
     n->mu = n->sigma = n->vs = nullptr;
     n->keep_level = 0;
     n->ar_ev0 = n->ar_ev1 = nullptr; n->ar_pending = 0; n->ar_calls = 0; n->ht_rollouts = n->ht_updates = 0; n->ht_rollout_ms = n->ht_train_enq_ms = n->ht_train_wait_ms = 0.0; n->ht_train_t0 = 0.0; n->ar_ms_total = 0.0; n->ar_ms_last = 0.f;
@@ -907,7 +933,7 @@ int grl_net_create(grl_handle *h, const grl_net_config *cfg, grl_net **out) {
     int rc = GRL_OK;
     auto A = [&](float **p, size_t cnt) { if (rc == GRL_OK) rc = nalloc(n, p, cnt); };
     A(&n->params, n->ho.total); A(&n->paramsT, n->ho.total); A(&n->adam_m, n->ho.total); A(&n->adam_v, n->ho.total);
-    A(&n->w3f, 576 * 64); A(&n->stats, 16); A(&n->w2corr, 4 * 576 * 128);
+    A(&n->w3f, 576 * 64); A(&n->stats, 16); A(&n->wpvT, (size_t)1024 * 256); A(&n->w2corr, 4 * 576 * 128);
     A(&n->tbgimg, 12800); A(&n->tbgz, 128); A(&n->tbgimg3, 5184); A(&n->tbgz3, 128); A(&n->tybg, 49 * 512);
     if (rc == GRL_OK) rc = nalloc(n, &n->tbglist, 4);
     int nlanes = (cfg->reserved & GRL_NET_F_SINGLE_STREAM) ? 1 : 4;      // measured at 32 768 envs: 1.41 / 1.22 / 1.16 / 1.13 / 1.14 s per update with 1 / 2 / 3 / 4 / 8

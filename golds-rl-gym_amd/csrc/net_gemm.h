@@ -644,6 +644,29 @@ struct EpiBiasActBits {
     __device__ __forceinline__ void store_bits(int r, int colbase, unsigned long long w, int) const { bits[(long)r * wpr + (colbase >> 6)] = w; }
 };
 
+// Two dense layers that read the SAME input as one launch (pol1 and v1 both read dense2's output d2, policy_v_network.py:40-52):
+// columns [0, half) are the first layer's (C0, bias0), columns [half, 2 half) the second's (C1, bias1, and the sign bits of what is
+// stored, as EpiBiasActBits keeps them).  The A tile is staged once for both and one launch is saved per forward pass.
+struct EpiBiasActSplit {
+    static constexpr bool kColSum = false, kAddAux = true;
+    static constexpr bool kRowBits = true;
+    float *C0, *C1;
+    int ldc, half;
+    const float *bias0, *bias1;
+    unsigned long long *bits;
+    int wpr;
+    __device__ __forceinline__ int row_aux_n(int, int) const { return 0; }
+    __device__ __forceinline__ float elem_aux(int, int c, int) const { return c < half ? bias0[c] : bias1[c - half]; }
+    __device__ __forceinline__ void store(int r, int c, float v, int, float ea) const {
+        if (c < half) C0[(long)r * ldc + c] = fmaxf(v + ea, 0.f);
+        else C1[(long)r * ldc + c - half] = fmaxf(v + ea, 0.f);
+    }
+    __device__ __forceinline__ bool bit(float v, float ea) const { return v + ea > 0.f; }
+    __device__ __forceinline__ void store_bits(int r, int colbase, unsigned long long w, int) const {
+        if (colbase >= half) bits[(long)r * wpr + ((colbase - half) >> 6)] = w;      // wave-uniform
+    }
+};
+
 struct EpiBiasDual {
     static constexpr bool kColSum = false, kAddAux = true;   // C[r][c] = v + bias[c] and C2[r][c] = relu(v + bias[c]): pre-activation and activation in one pass
     float *C, *C2;

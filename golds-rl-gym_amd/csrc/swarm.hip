@@ -507,7 +507,7 @@ int swarm_launch_step(grl_handle *h, const float *actions_dev, const double *act
 // runs every chunk of envs as its own pipeline (forward -> sample -> step -> bookkeeping) on one of a few streams, so the fp64
 // VALU-bound step of one chunk overlaps the MFMA GEMMs of the others.  `slot` < 16 selects the done counter (one per stream; the
 // finished envs of the range are listed at done_list + env_base).
-int swarm_launch_step_range(grl_handle *h, const float *actions_dev, int env_base, int count, int slot) {
+int swarm_launch_step_range(grl_handle *h, const float *actions_dev, int env_base, int count, int slot, bool counter_zeroed) {
     SwarmParams P = make_params(h);
     P.actions = actions_dev;
     P.actions64 = nullptr;
@@ -515,7 +515,7 @@ int swarm_launch_step_range(grl_handle *h, const float *actions_dev, int env_bas
     P.E = env_base + count;
     P.done_list = h->done_list + env_base;
     P.done_count = h->done_count + slot;
-    GRL_HIP(h, hipMemsetAsync(P.done_count, 0, sizeof(int32_t), h->stream));
+    if (!counter_zeroed) GRL_HIP(h, hipMemsetAsync(P.done_count, 0, sizeof(int32_t), h->stream));      // (the conv rollout's sampling kernel does it)
     if (h->cfg.flags & GRL_F_SWARM_FAST_MATH)
         hipLaunchKernelGGL((swarm_kernel<MODE_STEP, true>), dim3(nblocks(count)), dim3(SWARM_TPB), 0, h->stream, P);
     else

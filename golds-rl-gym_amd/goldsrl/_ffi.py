@@ -84,6 +84,7 @@ SIGNATURES = {
     "grl_timer_ms": (C.c_int, [_P, C.POINTER(C.c_float)]),
     "grl_swarm_step_f64": (C.c_int, [_P, _P]),
     "grl_swarm_step_opts": (C.c_int, [_P, _P, _I, _I]),
+    "grl_device_pci_address": (C.c_int, [_I, C.c_char_p, _SZ]),
     "grl_episodes_enable": (C.c_int, [_P, _I]),
     "grl_episodes_read": (C.c_int, [_P, _P, _I, C.POINTER(_I), C.POINTER(_I)]),
     "grl_episodes_running": (C.c_int, [_P, _P, _P]),
@@ -127,6 +128,14 @@ for _k, _v in FLD.items():
         _FIELD_DTYPE[_v] = np.int32
     else:
         _FIELD_DTYPE[_v] = np.float32
+
+
+def device_pci_address(device_id):
+    """'dddd:bb:dd.f' of HIP device `device_id`, or None (no such device / no GPU)."""
+    buf = C.create_string_buffer(32)
+    if load_library().grl_device_pci_address(int(device_id), buf, 32) != OK:
+        return None
+    return buf.value.decode() or None
 
 
 class Engine(object):

@@ -97,6 +97,61 @@ def gpu_local_cpus(ordinal, sysfs="/sys", env=None):
     return cpus, gpus[ordinal], node
 
 
+def pci_local_cpus(pci, sysfs="/sys"):
+    """(cores, NUMA node) next to the PCI device `pci` ('dddd:bb:dd.f'), or (None, None)."""
+    dev = os.path.join(sysfs, "bus", "pci", "devices", pci)
+    try:
+        with open(os.path.join(dev, "local_cpulist")) as f:
+            cpus = parse_cpulist(f.read())
+    except (OSError, ValueError):
+        return None, None
+    node = None
+    try:
+        with open(os.path.join(dev, "numa_node")) as f:
+            node = int(f.read().strip())
+    except (OSError, ValueError):
+        pass
+    return (cpus or None), node
+
+
+def pin_to_pci(pci, sysfs="/sys", env=None, apply=True):
+    """The same restriction for a caller that already knows its GPU's PCI address -- from the HIP runtime
+    (_ffi.device_pci_address) where the KFD topology is not readable (containers that hide /sys/class/kfd's GPU nodes).  The
+    runtime is up by then, so only the CALLING thread moves (the one that enqueues the launches); its helper threads keep the mask
+    they were born with."""
+    env = os.environ if env is None else env
+    rep = {"pinned": False, "pci": pci, "via": "hipDeviceGetPCIBusId"}
+    if env.get("GRL_PIN_CPUS", "on").lower() in ("off", "0", "no"):
+        rep["reason"] = "GRL_PIN_CPUS=off"
+        return rep
+    if not pci or not hasattr(os, "sched_setaffinity"):
+        rep["reason"] = "no PCI address / no sched_setaffinity"
+        return rep
+    cpus, node = pci_local_cpus(pci, sysfs)
+    if cpus is None:
+        rep["reason"] = "no local_cpulist for %s" % pci
+        return rep
+    rep["numa_node"] = node
+    try:
+        allowed = os.sched_getaffinity(0)
+    except OSError as e:
+        rep["reason"] = "sched_getaffinity: %s" % e
+        return rep
+    use = cpus & allowed
+    rep["allowed_cpus"], rep["node_cpus"] = len(allowed), len(cpus)
+    if not use:
+        rep["reason"] = "the GPU's cores and the cores this process may use do not intersect"
+        return rep
+    if use != allowed and apply:
+        try:
+            os.sched_setaffinity(0, use)
+        except OSError as e:
+            rep["reason"] = "sched_setaffinity: %s" % e
+            return rep
+    rep.update(pinned=True, cpus=len(use))
+    return rep
+
+
 def pin_to_gpu(ordinal, sysfs="/sys", env=None, apply=True):
     """Restrict this process to the cores of the GPU's NUMA node.  Call BEFORE the first HIP call (threads the runtime starts
     afterwards inherit the mask).  Returns a small report for the bench line / the log; never raises."""

@@ -197,6 +197,9 @@ int grl_swarm_step_f64(grl_handle *h, const double *actions_host);
  * v_calculate, multiagent.py:39, does not depend on it).  add_wind = 1 is grl_step_async / grl_swarm_step_f64. */
 int grl_swarm_step_opts(grl_handle *h, const void *actions_host, int32_t actions_f64, int32_t add_wind);
 int grl_wait(grl_handle *h);                       /* hipStreamSynchronize + deferred error checks */
+/* PCI address "dddd:bb:dd.f" of HIP device `device_id` (hipDeviceGetPCIBusId), for callers that place their host thread next to
+ * the GPU (goldsrl/affinity.py; the reference leaves its worker processes' placement to the OS, runners.py:34-36).  `bytes` >= 16. */
+int grl_device_pci_address(int32_t device_id, char *out, size_t bytes);
 int grl_outputs(grl_handle *h, grl_out_ptrs *out); /* device pointers */
 /* Copy one output to the host: which = name of a grl_out_ptrs member, e.g. "reward". */
 int grl_read_output(grl_handle *h, const char *which, void *host, size_t bytes);

@@ -63,3 +63,14 @@ def test_pin_intersects_with_the_allowed_cores_and_can_be_switched_off(tmp_path)
             "assert r['pinned'], r; assert sorted(os.sched_getaffinity(0)) == %r; print('ok')" % (os.path.join(ROOT, "golds-rl-gym_amd"), sysfs, half))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
     assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr
+
+
+def test_pin_by_pci_address_fallback(tmp_path):
+    """Where sysfs hides the KFD GPU nodes the PCI address comes from the runtime (grl_device_pci_address); the rest is the same."""
+    from goldsrl import affinity as A
+    allowed = sorted(os.sched_getaffinity(0))
+    sysfs = _fake_sysfs(tmp_path, [(0, 0x75, 0, 0, ",".join(str(c) for c in allowed[:1]), 1)])
+    rep = A.pin_to_pci("0000:75:00.0", sysfs, {}, apply=False)
+    assert rep["pinned"] and rep["cpus"] == 1 and rep["numa_node"] == 1 and rep["via"] == "hipDeviceGetPCIBusId"
+    assert A.pin_to_pci("0000:76:00.0", sysfs, {}, apply=False)["pinned"] is False
+    assert A.pin_to_pci(None, sysfs, {})["pinned"] is False
