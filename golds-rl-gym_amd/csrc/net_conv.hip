@@ -126,6 +126,7 @@ struct NetLane {
     float *ws_sraw, *ws_a2sh, *ws_d2s;
     unsigned long long *ws_m2s;
     signed char *ws_ulist;
+    void *ws_idx[24];          // the chunk workspace of the index lists GRL_IDX_LIST names (bound like the activations at keep level 3)
     bool train_ready;
 };
 
@@ -638,11 +639,31 @@ __global__ void sample_actions_kernel(const float *__restrict__ mu, const float 
 // ------------------------------------------------------------------------------------------ forward pass of one chunk
 // floats kept per chunk slot: per-agent-trunk mode a3 + dense stack; shared mode a3sh (per env) + d3 + patch mask + dense stack,
 // and at level 2 also what the gradient step reads of the per-env trunk: sraw, a2sh (per env), d2s, slot mask, ulist (per slot)
+// What the gradient step reads of a chunk's index lists (slot_index, slot_sort, patch_sort, trunk_index): at keep level 3 the
+// rollout's forward pass writes them into the chunk's resident slot and the gradient step finds them there, instead of running the 17
+// index kernels of a chunk a second time (340 launches and ~3 ms of kernel time per 8 192-env update).  X(member, bytes).
+#define GRL_IDX_LIST(X)                                                                                                             \
+    X(perm, (size_t)net->ptiles * 256 * 4) X(sbeg, (size_t)net->pslices * 4) X(send, (size_t)net->pslices * 4)                      \
+    X(sgrp, (size_t)net->pslices * 4) X(smask, c * 4) X(tmask, ((size_t)net->ptiles * 2 + 2) * 4) X(zmask, (size_t)net->pslices * 4) \
+    X(tilegroup, (size_t)net->ptiles) X(org, c) X(sbase, (c + 1) * 4) X(rowagent, c * 9 * 4) X(stap, c * 9 * 2)                     \
+    X(sperm, (c * 9 + 256) * 4) X(stmask, ((c * 9 + 255) / 256 + 1) * 4) X(tamask, ((c / 10) * 3 + 3) * 4)                          \
+    X(tcmask, ((c / 10) * 2 + 2) * 4) X(trowlist, ((c / 10) * 81 + 256) * 4) X(tblklist, ((c / 10) * 100 + 256) * 4)               \
+    X(tc3list, ((c / 10) * 49 + 256) * 4) X(trows_n, 16) X(tumask, 16)
+static size_t idx_bytes_per_slot(const grl_net *net) {
+    const size_t c = net->chunk;
+    size_t b = 0;
+#define X(m, bytes) b += ((size_t)(bytes) + 127) & ~(size_t)127;
+    GRL_IDX_LIST(X)
+#undef X
+    return b;
+}
+
 static size_t keep_floats_per_slot(const grl_net *net, int level) {
     const size_t c = net->chunk, dense = 512 + 256 + 512 + 512 + 256 + 32;      // + the sign bits of d2 and v1 (12 words per sample, padded to 16)
     if (!net->shared_trunk) return c * (3136 + dense);
     size_t f = (c / 10) * 3136 + c * (1600 + 50 + dense);      // m3: 25 x 8 bytes per sample
     if (level >= 2) f += (c / 10) * (12800 + 5184) + c * (576 + 18) + ((c * 9 + 3) / 4 + 3) / 4 * 4;      // stays a multiple of 16 bytes
+    if (level >= 3) f = ((f + 31) & ~(size_t)31) + idx_bytes_per_slot(net) / 4;      // every list on its own 128-byte line, the slot a multiple of 128 bytes
     return f;
 }
 
@@ -653,6 +674,12 @@ static void bind_activations(grl_net *net, long slot) {
     net->a3sh = net->ws_a3sh; net->d3 = net->ws_d3; net->m3 = net->ws_m3;
     net->mb_d2 = net->ws_mb; net->mb_v1 = net->ws_mb + (size_t)net->chunk * 4;
     net->sraw = net->ws_sraw; net->a2sh = net->ws_a2sh; net->d2s = net->ws_d2s; net->m2s = net->ws_m2s; net->ulist = net->ws_ulist;
+    if (net->ws_idx[0]) {
+        int k = 0;
+#define X(m, bytes) net->m = static_cast<decltype(net->m)>(net->ws_idx[k++]);
+        GRL_IDX_LIST(X)
+#undef X
+    }
     if (slot < 0 || !net->keep) return;
     const size_t c = net->chunk;
     float *b = net->keep + (size_t)slot * keep_floats_per_slot(net, net->keep_level);
@@ -674,7 +701,14 @@ static void bind_activations(grl_net *net, long slot) {
         net->a2sh = b; b += (c / 10) * 5184;
         net->d2s = b; b += c * 576;
         net->m2s = reinterpret_cast<unsigned long long *>(b); b += c * 18;      // 9 words per sample
-        net->ulist = reinterpret_cast<signed char *>(b);
+        net->ulist = reinterpret_cast<signed char *>(b); b += ((c * 9 + 3) / 4 + 3) / 4 * 4;
+    }
+    if (net->shared_trunk && net->keep_level >= 3) {
+        const size_t used = (size_t)(b - (net->keep + (size_t)slot * keep_floats_per_slot(net, net->keep_level)));
+        char *q = reinterpret_cast<char *>(b + (((used + 31) & ~(size_t)31) - used));
+#define X(m, bytes) net->m = reinterpret_cast<decltype(net->m)>(q); q += ((size_t)(bytes) + 127) & ~(size_t)127;
+        GRL_IDX_LIST(X)
+#undef X
     }
 }
 
@@ -689,7 +723,11 @@ static int forward_chunk(grl_net *net, const uint8_t *lb, const uint8_t *ab, con
     if (net->shared_trunk) {
         // gradient step on resident activations: at level 2 the trunk tensors are resident too, only the group sort reruns
         int rc;
-        if (reuse_tail && net->keep_level >= 2) {
+        if (reuse_tail && net->keep_level >= 3) {
+            // the rollout's index lists are resident with its activations (bind_activations): nothing to rebuild
+            if ((rc = slot_prof(net, n))) return rc;
+            rc = patch_prof(net);
+        } else if (reuse_tail && net->keep_level >= 2) {
             if ((rc = slot_index(net, pos, n))) return rc;
             if (net->trunk_skip && net->expand2_gemm && (rc = trunk_index(net, lb, ab, pos, nenv))) return rc;      // the gradient step's row lists
             rc = patch_sort(net, n);
@@ -837,6 +875,14 @@ static int alloc_lane_forward(grl_net *n) {
     if (rc == GRL_OK) rc = nalloc(n, &n->cgoff, 8);
     if (rc == GRL_OK) rc = nalloc(n, &n->cslot, c * 9);
     if (rc == GRL_OK) rc = nalloc(n, &n->ctilegroup, (size_t)n->ctiles);
+    if (rc == GRL_OK) {
+        grl_net *net = n;
+        int k = 0;
+#define X(m, bytes) net->ws_idx[k++] = (void *)net->m;
+        GRL_IDX_LIST(X)
+#undef X
+        static_assert(sizeof(((NetLane *)nullptr)->ws_idx) / sizeof(void *) >= 21, "ws_idx holds every list of GRL_IDX_LIST");
+    }
     return rc;
 }
 
