@@ -73,6 +73,9 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the rollout_only / env_only side measurements")
     ap.add_argument("--cpu-sample-envs", type=int, default=2048)
     ap.add_argument("--no-strong", action="store_true", help="N>1: skip the strong-scaling point (32 768 envs in total)")
+    ap.add_argument("--interior", action="store_true",
+                    help="profiling aid: run the main measurement on the interior_policy state distribution (agents re-injected into the "
+                         "interior of the box before every update, outside the clock)")
     ap.add_argument("--no-legs", action="store_true", help="skip the dense_form / interior_policy legs (two more 32 768-env jobs)")
     ap.add_argument("--no-flat-configs", action="store_true", help="skip the Solow-4096 / TradeAR1-16 side blocks (configs 2 and 5)")
     ap.add_argument("--exchange", default="rccl", choices=["rccl", "host"],
@@ -203,18 +206,20 @@ def timed(run, wait, steps):
     return time.perf_counter() - t0
 
 
-def timed_each(run, wait, steps):
+def timed_each(run, wait, steps, before=None):
     """K updates, the clock read after each one has drained (an update ends in a stream synchronisation anyway: its statistics
-    come back to the host, paac.py:189-194).  Returns (total seconds, [seconds per update])."""
-    per, t0 = [], time.perf_counter()
-    t_prev = t0
+    come back to the host, paac.py:189-194).  `before` runs ahead of every update, off the clock.  Returns (total seconds, [seconds
+    per update])."""
+    per, total = [], 0.0
     for _ in range(steps):
+        if before:
+            before()
+        t0 = time.perf_counter()
         run()
         wait()
-        t = time.perf_counter()
-        per.append(t - t_prev)
-        t_prev = t
-    return t_prev - t0, per
+        per.append(time.perf_counter() - t0)
+        total += per[-1]
+    return total, per
 
 
 def spread(per_s):
@@ -362,7 +367,11 @@ def measure_swarm(args, ranks, E, T, want_roofline, label):
         roll.run()
     barrier()
     ht0 = net.host_times() if net is not None else None
-    elapsed, per_update = timed_each(roll.run, eng.wait, args.steps)
+    before = None
+    if getattr(args, "interior", False):
+        irng = np.random.RandomState(4)
+        before = lambda: inject_interior_agents(eng, irng)      # noqa: E731
+    elapsed, per_update = timed_each(roll.run, eng.wait, args.steps, before)
     ht1 = net.host_times() if net is not None else None
     ranks.barrier()
     elapsed = ranks.max(elapsed)

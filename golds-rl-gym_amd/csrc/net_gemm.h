@@ -969,21 +969,30 @@ __device__ __forceinline__ int swz(int row) { return (0x78 >> (((row >> 2) & 3) 
 // 64 lanes on 32 banks twice, the minimum for a 4-byte read).  One K = 32 step is eight v_mfma_f32_16x16x4_f32 per 16 x 16 tile
 // into ONE accumulator set: no operand range beyond fp32's, 5.3x the matrix-pipe time of the three-product form (measured: 103 TFLOP/s over the update's GEMMs, 0.65 of the 157 TFLOP/s fp32-MFMA peak).
 __device__ __forceinline__ int f32_off(int row, int k) { return row * 32 + ((((k >> 2) ^ (row & 7)) << 2) | (k & 3)); }
+// The reduction order inside a K = 32 tile is free as long as both operands use the same one: lane (row l & 15, group kg = l >> 4)
+// takes k = 8 kg .. 8 kg + 7 -- two 16-byte chunks of its row, i.e. two ds_read_b128 per fragment -- and MFMA j multiplies the j-th of
+// them (round 4; until then k = 4 j + kg: eight ds_read_b32 per fragment, and the loop was bound by LDS issue at 0.65 of the fp32
+// matrix-pipe peak).  The chunk swizzle keeps the reads conflict-free: a quarter wave's 16 rows hit chunk (2 kg [+ 1]) ^ (row & 7).
 template <int TM, int TN>
 __device__ __forceinline__ void mfma_f32_step(const float *__restrict__ Af, const float *__restrict__ Bf, int arow, int brow, int kg,
                                               f32x4 (&acc)[TM][TN]) {
+    float4 a0[TM], a1[TM], b0[TN], b1[TN];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        float av[TM], bv[TN];
-#pragma unroll
-        for (int a = 0; a < TM; ++a) av[a] = Af[f32_off(arow + a * 16, 4 * j + kg)];
-#pragma unroll
-        for (int b = 0; b < TN; ++b) bv[b] = Bf[f32_off(brow + b * 16, 4 * j + kg)];
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-            for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+    for (int a = 0; a < TM; ++a) {
+        a0[a] = *reinterpret_cast<const float4 *>(Af + f32_off(arow + a * 16, 8 * kg));
+        a1[a] = *reinterpret_cast<const float4 *>(Af + f32_off(arow + a * 16, 8 * kg + 4));
     }
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+        b0[b] = *reinterpret_cast<const float4 *>(Bf + f32_off(brow + b * 16, 8 * kg));
+        b1[b] = *reinterpret_cast<const float4 *>(Bf + f32_off(brow + b * 16, 8 * kg + 4));
+    }
+#define GRL_F32_STEP(AV, BV)                                                                                          \
+    _Pragma("unroll") for (int a = 0; a < TM; ++a)                                                                    \
+        _Pragma("unroll") for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV, BV, acc[a][b], 0, 0, 0);
+    GRL_F32_STEP(a0[a].x, b0[b].x) GRL_F32_STEP(a0[a].y, b0[b].y) GRL_F32_STEP(a0[a].z, b0[b].z) GRL_F32_STEP(a0[a].w, b0[b].w)
+    GRL_F32_STEP(a1[a].x, b1[b].x) GRL_F32_STEP(a1[a].y, b1[b].y) GRL_F32_STEP(a1[a].z, b1[b].z) GRL_F32_STEP(a1[a].w, b1[b].w)
+#undef GRL_F32_STEP
 }
 
 // optional hooks of a gather descriptor: whole output column tiles (gemm_rowk) / output row tiles (gemm_tn) known to be zero

@@ -670,7 +670,7 @@ def test_trunk_row_lists_change_nothing_but_the_work(monkeypatch, layout):
         res[mode] = (out, stats, g1)
         net.close()
     for k in ("mu", "sigma", "vs"):      # conv1-conv3: the same bits; dense1's per-env part adds the background pixels' share as one term
-        np.testing.assert_allclose(res["on"][0][k], res["off"][0][k], rtol=2e-6, atol=1e-7, err_msg=k)
+        np.testing.assert_allclose(res["on"][0][k], res["off"][0][k], rtol=2e-6, atol=2e-7, err_msg=k)      # (1.3e-7 on the fp32 form, GRL_NET_GEMM=f32)
     np.testing.assert_allclose(list(res["on"][1].values()), list(res["off"][1].values()), rtol=1e-6)
     gon, goff = NN.unflatten_params(res["on"][2].astype(np.float64)), NN.unflatten_params(res["off"][2].astype(np.float64))
     for k in gon:
