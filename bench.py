@@ -53,7 +53,7 @@ MFMA_F16_PEAK_TFLOPS = 2516.6        # MI355X_MICROARCH.md: dense fp16 / bf16 ma
 # bf16 split with SIX products: peak 419.4, same kernels otherwise -- the fraction is not comparable across that change.)
 F16_PRODUCTS_PER_FP32 = 3
 MFMA_X3_PEAK_TFLOPS = MFMA_F16_PEAK_TFLOPS / F16_PRODUCTS_PER_FP32
-GEMM_TRAFFIC_FILE = "r03_gemm_traffic.json"   # PMC pass of the GEMM kernels (tools/run_prof.sh); refreshed per round
+GEMM_TRAFFIC_FILE = "r04_gemm_traffic.json"   # PMC pass of the GEMM kernels (tools/run_prof.sh); refreshed per round
 
 
 def parse():
@@ -571,11 +571,12 @@ def main():
         if gemm is not None:
             launches, ms, flops = gemm
             ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-            gtraffic = None      # HBM bytes per GEMM launch from the committed PMC passes (same 81 920-sample chunks)
+            gtraffic, gfam = None, {}      # HBM bytes per GEMM launch from the committed PMC passes (same 81 920-sample chunks)
             gpath = os.path.join(ROOT, "profiles", GEMM_TRAFFIC_FILE)
             if os.path.exists(gpath):
                 with open(gpath) as f:
-                    gtraffic = json.load(f).get("hbm_bytes_per_launch")
+                    gj = json.load(f)
+                gtraffic, gfam = gj.get("hbm_bytes_per_launch"), gj.get("by_family", {})
             out["roofline"] = {"bound": "mfma",
                                "kernel": "gemm_rowk / gemm_tn (fp32 implicit GEMMs: operands split into 2 fp16 terms, "
                                          "3 v_mfma_f32_16x16x32_f16 per 16x16 tile and K=32 step, fp32 accumulation)",
@@ -607,6 +608,18 @@ def main():
                                "by_family": {k: {"launches": v[0], "ms": v[1], "achieved": v[2] / (v[1] * 1e-3) / 1e12 if v[1] > 0 else 0.0,
                                                  "frac": (v[2] / (v[1] * 1e-3) / 1e12 / MFMA_X3_PEAK_TFLOPS) if v[1] > 0 else 0.0}
                                              for k, v in gemm_tags.items()}}
+            # which roof a family is nearer: the live duration of its launches against the matrix pipe (frac) and against HBM (hbm_frac:
+            # HBM-side bytes per launch of the committed PMC passes of the same chunk size / the live average launch duration / 8 TB/s);
+            # the N <= 64 families (conv gathers, slots, class corrections) are byte bound, the square dense ones sit under both roofs
+            for k, v in out["roofline"]["by_family"].items():
+                pf = gfam.get(k)
+                if pf and v["launches"] > 0 and v["ms"] > 0:
+                    tbps = pf["hbm_bytes_per_launch"] / (v["ms"] * 1e-3 / v["launches"]) / 1e12
+                    v["hbm_bytes_per_launch"] = pf["hbm_bytes_per_launch"]
+                    v["hbm_TBps"] = tbps
+                    v["hbm_frac"] = tbps / (HBM_PEAK_GBS / 1e3)
+                    v["bound"] = "hbm" if v["hbm_frac"] > v["frac"] else "mfma"
+                    v["traffic_source"] = "from_profile: profiles/%s" % GEMM_TRAFFIC_FILE
             # SURVEY 8(d)'s algorithmic figure: the reference evaluates the net once per agent-sample, 18.10 MFLOP forward, backward = 2x
             # forward; an update = (T + 1) rollout forwards + T training forwards and backwards over E * 10 agent-samples
             contract_flops = 18.10e6 * 10 * E * ((T + 1) + (0 if args.no_train else 3 * T))

@@ -189,10 +189,12 @@ __device__ __forceinline__ int count_edges_le(double v, double lo, double hi, do
 enum { MODE_STEP = 0, MODE_OBSERVE = 1, MODE_RESET = 2 };
 
 template <int MODE, bool FAST>
-// The step's pair loop is a long chain of dependent fp64 operations (two exp polynomials, three divisions per pair): six waves per SIMD
-// instead of the four its 124 registers allowed hide more of it -- 0.976 -> 0.859 ms per 32 768-env step with 80 registers and 104 bytes of
-// scratch per lane (5 / 6 / 7 / 8 waves: 0.875 / 0.859 / 0.875 / 0.863 ms; round 4).  The second launch bound is waves per SIMD.
-__global__ __launch_bounds__(SWARM_TPB, MODE == 0 ? 6 : 1) void swarm_kernel(SwarmParams P) {
+// The step's pair loop is a long chain of dependent fp64 operations (two exp polynomials, three divisions per pair): five waves per SIMD
+// instead of the four its 124 registers allowed hide more of it -- 0.976 -> 0.875 ms per 32 768-env step with 96 registers and 24 bytes of
+// scratch per lane (round 4).  Six waves (80 registers, 104 bytes of scratch) measured 0.859 ms but tripled the kernel's HBM-side bytes
+// (each lane writes and reads its spill slots once: 488 MB per launch against 151 MB algorithmic); 7 / 8 waves: 0.875 / 0.863 ms.
+// The second launch bound is waves per SIMD.
+__global__ __launch_bounds__(SWARM_TPB, MODE == 0 ? 5 : 1) void swarm_kernel(SwarmParams P) {
     __shared__ SwarmLds L;
     __shared__ int env_of[SWARM_EPB];
     const int tid = threadIdx.x;
