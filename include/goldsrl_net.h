@@ -15,7 +15,7 @@
  * measures closer to a float64 evaluation than a plain float32 one.  Range contract of that form: activations and weights
  * below 65 504 in magnitude.  Nothing is clamped: every GEMM checks its output tile, and the first call that synchronises
  * after a violation (predict, train_*, apply_grads) does not return results computed from inf operands.  By default it switches the
- * net to the fp32 form of the same GEMM kernels (v_mfma_f32_16x16x4_f32, no range beyond float32's, measured 103 TFLOP/s = 0.65 of the fp32-MFMA peak, an update takes 0.91 s instead of 0.57; the net
+ * net to the fp32 form of the same GEMM kernels (v_mfma_f32_16x16x4_f32, no range beyond float32's, an update of the headline configuration takes 0.50 s instead of 0.33: 1.5x, round 4; the net
  * stays there until grl_net_set_gemm_f32(net, 0)) and runs the work again: predict and train_obs in full; a gradient step over a
  * rollout runs again when only its backward pass overflowed, and is given up (GRL_OK, NaN statistics, update_skipped = 1 in
  * grl_net_range_info; parameters and Adam moments untouched) when the rollout's own forward passes did -- the next rollout is valid.
