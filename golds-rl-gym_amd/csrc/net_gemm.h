@@ -918,12 +918,7 @@ __global__ __launch_bounds__(256) void fold_class_sums_kernel(const float *__res
         partial[blockIdx.x * 32 + threadIdx.x] = t;
     }
 }
-__global__ __launch_bounds__(64) void fold_class_final_kernel(const float *__restrict__ partial, float *__restrict__ dst) {
-    if (threadIdx.x >= 32) return;
-    float t = 0.f;
-    for (int w = 0; w < kFoldParts; ++w) t += partial[w * 32 + threadIdx.x];
-    dst[threadIdx.x] += t;
-}
+// (fold_class_final_kernel: its body is a job of reduce_batch_kernel since round 4, net_reduce.inc)
 
 // ---------------------------------------------------------------------------- fp32 operands on the fp16 matrix pipe
 // (x, y) -> packed fp16 pairs h = fp16(.), l = fp16((. - h) * 2^11); 3 VALU instructions per element (v_cvt_pk_f16_f32,
@@ -1514,42 +1509,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void gemm_tn(AG ag, 
 #undef GRL_TN_OFF
 }
 
-// dst[i] (+)= sum_c slab[c][i]   (fixed association: 4 strided partial sums, then a fixed tree -> bitwise
-// reproducible, and four independent load streams per lane)
-__global__ void slab_reduce_kernel(const float *__restrict__ slab, int chunks, long n, float *__restrict__ dst, int accumulate) {
-    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int c = 0;
-    for (; c + 3 < chunks; c += 4) {
-        s0 += slab[(long)c * n + i];
-        s1 += slab[(long)(c + 1) * n + i];
-        s2 += slab[(long)(c + 2) * n + i];
-        s3 += slab[(long)(c + 3) * n + i];
-    }
-    for (; c < chunks; ++c) s0 += slab[(long)c * n + i];
-    float s = (s0 + s1) + (s2 + s3);
-    dst[i] = accumulate ? dst[i] + s : s;
-}
+// (slab_reduce_kernel: its body is a job of reduce_batch_kernel since round 4, net_reduce.inc)
 
-// groups of slabs reduced in one launch: dst[g][i] (+)= sum_c slab[g * chunks + c][i]
-__global__ void slab_reduce_groups_kernel(const float *__restrict__ slab, int chunks, int n, int groups, float *__restrict__ dst, int accumulate) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= groups * n) return;
-    const int g = e / n, i = e - g * n;
-    const float *sl = slab + (long)g * chunks * n + i;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int c = 0;
-    for (; c + 3 < chunks; c += 4) {
-        s0 += sl[(long)c * n];
-        s1 += sl[(long)(c + 1) * n];
-        s2 += sl[(long)(c + 2) * n];
-        s3 += sl[(long)(c + 3) * n];
-    }
-    for (; c < chunks; ++c) s0 += sl[(long)c * n];
-    const float s = (s0 + s1) + (s2 + s3);
-    dst[e] = accumulate ? dst[e] + s : s;
-}
+// (slab_reduce_groups_kernel: its body is a job of reduce_batch_kernel since round 4, net_reduce.inc)
 
 // Same for a short row (n up to a few thousand) and many chunks, where one lane per element would walk the chunks
 // serially: 4 elements per workgroup, a wave per element -- lane p sums the chunks p, p + 64, ... in four interleaved partial sums,
