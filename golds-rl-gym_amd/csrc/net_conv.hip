@@ -154,6 +154,7 @@ struct grl_net : NetLane {
     int patch_skip;            // 1: the dense1 patch GEMMs skip what the support masks say is zero (GRL_PATCH_SKIP=off: the plain 5x5 patch)
     int gemm_f32, range_fallback_on, range_fallbacks, range_bits_last, update_skipped_last;
     int loss_scale_on;         // per-pass power-of-two scale of the head gradients (net_train.inc); GRL_NET_LOSS_SCALE=off disables it
+    int expand3_gather;        // conv3's per-agent corrections as a gather GEMM at the patch pixels (default; GRL_NET_EXPAND3=prod: slot products + expansion kernel)
     int expand2_gemm, ctiles;  // conv2's per-agent corrections as a class-sorted GEMM (default) or the LDS-resident kernel (GRL_NET_EXPAND2=lds)
     float *w2corr;             // [4 classes][576][128] kernel slices of that GEMM, rebuilt with the transposes
     grl::HeadOff ho;           // offsets of the head / value parameters for this net's num_actions
@@ -748,7 +749,7 @@ static int forward_chunk(grl_net *net, const uint8_t *lb, const uint8_t *ab, con
     }
     if (!reuse_tail) {
     if (net->shared_trunk) {
-        if (int rc = forward_conv3_dense1_shared(net, nenv)) return rc;
+        if (int rc = forward_conv3_dense1_shared(net, nenv, pos)) return rc;
     } else {
         GatherConv3 g{net->a2, n * 49};
         EpiBiasAct e{net->a3, 64, P + ConvOffsets::c3b, ACT_RELU};
@@ -965,6 +966,7 @@ int grl_net_create(grl_handle *h, const grl_net_config *cfg, grl_net **out) {
         n->pfrac[0] = n->pfrac[1] = n->pfrac[2] = 1.0; n->sfrac = 1.0;
         const char *e2 = getenv("GRL_NET_EXPAND2");
         n->expand2_gemm = (e2 && strcmp(e2, "lds") == 0) ? 0 : 1;
+        { const char *e3 = getenv("GRL_NET_EXPAND3"); n->expand3_gather = (e3 && strcmp(e3, "prod") == 0) ? 0 : 1; }
     }
     n->pslice_rows = PATCH_SLICE_ROWS; n->pwgrad_xcd = 1;      // a row slice per XCD: A and B of a slice fetched once (under the support masks and the lighter traffic of round 3 this order wins by 0.7 %; 2 was the choice for the plain patch)
     if (const char *e = getenv("GRL_PATCH_SLICE")) { const int v = atoi(e); if (v == 256 || v == 512 || v == 1024 || v == 2048 || v == 4096 || v == 8192) n->pslice_rows = v; }

@@ -303,7 +303,9 @@ struct DenseRows {   // plain row-major [rows][ld], reduction length k
 // weight gradient writes no slab tile for their rows (rank-1 closed form).
 struct DenseRowsKU : DenseRows {
     const unsigned *u;
-    __device__ __forceinline__ bool tile_ok(int, int k0) const { return (u[k0 >> 11] >> ((k0 >> 6) & 31)) & 1u; }
+    __device__ __forceinline__ unsigned long long wg_ctx(int) const { return (unsigned long long)u[0] | ((unsigned long long)u[1] << 32); }
+    __device__ __forceinline__ bool tile_ok_c(unsigned long long c, int k0) const { return (c >> (k0 >> 6)) & 1ull; }
+    __device__ __forceinline__ int bk_c(unsigned long long, int k0) const { return k0; }
 };
 struct DenseRowsNU : DenseRows {
     const unsigned *u;
@@ -487,10 +489,11 @@ struct SlotGatherT3P {
         return (unsigned)(iy0 + ty) < 7u && (unsigned)(ix0 + tx) < 7u;
     }
     // the masks are in the forward's tap numbering (output u - t); this gather's tap (ty, tx) reads output u - 2 + t: tap 8 - k there
-    __device__ __forceinline__ bool tile_ok(int m0, int k0) const { return !tmask || ((tmask[m0 >> 8] >> (8 - (k0 >> 6))) & 1u); }
+    __device__ __forceinline__ unsigned wg_ctx(int m0) const { return tmask ? tmask[m0 >> 8] : 0x1FFu; }
+    __device__ __forceinline__ bool tile_ok_c(unsigned c, int k0) const { return (c >> (8 - (k0 >> 6))) & 1u; }
+    __device__ __forceinline__ int bk_c(unsigned, int k0) const { return k0; }
     __device__ __forceinline__ bool tile_active(int m0) const { return m0 < *rows_dev; }
     __device__ __forceinline__ bool i_ok(int z, int i0) const { return !zmask || ((zmask[z] >> (8 - (i0 >> 6))) & 1u); }
-    __device__ __forceinline__ int bk(int k0, int) const { return k0; }
     __device__ __forceinline__ int bn(int n0, int) const { return n0; }
     // gemm_tn: row handles are fetched one tile ahead of the data (ahandle / bhandle may load), rowh is arithmetic only
     __device__ __forceinline__ int2 ahandle(int m) const { return rowdesc[m]; }
@@ -502,6 +505,45 @@ struct SlotGatherT3P {
     }
 };
 
+
+// conv3's per-agent corrections GATHERED at the patch pixels (round 4; replaces the slot-product tensor and its expansion kernel in
+// the forward pass).  Row = one (sample, patch pixel q) item some dense1 GEMM may read (net_patch.inc, wmask); k = (tap, ci):
+//     A[row][t * 64 + ci] = (a2_a - a2sh)[u = r + t][ci]   where the agent has touched conv2 pixel u, else 0,
+// against conv3's own kernel W3[t][ci][co]: the accumulator IS the agent's correction of conv3's pre-activation at pixel r, and the
+// epilogue (EpiPatchExpand) finishes what expand_conv3_patch_kernel did.  The agent's touched pixels are read from the CANONICAL
+// 3 x 3 cell block d2c[sample][jy][jx][64] (jy = H - uy: conv2_prep's canonical grid), so that the address of tap t is linear in t:
+// offset of tap (0, 0) + toff, toff = -(ty * 3 + tx) * 64, the same for every row of a tile; a cell exists where cy0 - ty lies in
+// the agent's valid cell range [lo, hi] (per axis; packed with cy0 + 8 into the row's 16-bit iy0 / ix0).  Rows come sorted by patch
+// pixel (all samples' pixel q together, samples in patch-sort order), so a 256-row tile's union of live taps (tmask) is tight and
+// tile_ok skips the K-tiles of dead taps: the executed FLOPs are those of the slot-product form, without its 0.45-3.4 GB round trip
+// through memory per chunk.
+struct SlotsToPatch {
+    static constexpr bool kRelu = false;
+    const float *base;               // d2c
+    const int4 *desc;                // per sorted row: {code (EpiPatchExpand), element offset of tap (0,0) in d2c, live kernel rows << 3 | columns, spare}
+    int rows;                        // upper bound (25 per sample); the live count is *rows_dev
+    const int *rows_dev;
+    const unsigned short *tmask;     // per 128-row tile: union of the rows' live taps (bit t = ty * 3 + tx)
+    __device__ __forceinline__ int K() const { return 576; }
+    __device__ __forceinline__ void row(int r, long &off, int &iy0, int &ix0) const {
+        const int4 d = desc[r];
+        off = d.y;
+        iy0 = d.z >> 3;      // the kernel rows that reach one of the agent's cells from this pixel (3 bits) ...
+        ix0 = d.z & 7;       // ... and the columns
+    }
+    __device__ __forceinline__ void tap(int k0, int &toff, int &ty, int &tx) const {
+        const int t = k0 >> 6;
+        ty = t / 3;
+        tx = t - ty * 3;
+        toff = -(ty * 3 + tx) * 64 + (k0 & 63);      // tap (ty, tx) reads the cell (ty, tx) steps before the one of tap (0,0)
+    }
+    __device__ __forceinline__ bool ok(int iy0, int ix0, int ty, int tx) const { return ((iy0 >> ty) & (ix0 >> tx) & 1) != 0; }
+    __device__ __forceinline__ unsigned wg_ctx(int m0) const { return tmask ? (unsigned)tmask[m0 >> 7] : 0x1FFu; }      // gemm_rowk, BM = 128
+    __device__ __forceinline__ bool tile_ok_c(unsigned c, int k0) const { return (c >> (k0 >> 6)) & 1u; }
+    __device__ __forceinline__ int bk_c(unsigned, int k0) const { return k0; }
+    __device__ __forceinline__ bool tile_active(int m0) const { return m0 < *rows_dev; }
+    __device__ __forceinline__ int bn(int n0, int) const { return n0; }
+};
 
 // dense1 on the shared a3 (net_patch.inc): an agent's a3 differs from its env's a3sh only inside a 5x5 window ("patch",
 // origin (oy, ox) in {0,1,2}^2 = group g) of the 7x7 map.  Samples are sorted by group into 256-row tiles (perm[slot] =
@@ -552,16 +594,23 @@ struct PatchRows {
         ty = tx = 0;
     }
     __device__ __forceinline__ bool ok(int iy0, int, int, int) const { return iy0 >= 0; }
-    __device__ __forceinline__ bool tile_ok(int m0, int k0) const {      // gemm_rowk, BM = 128, mode 0: K-tile k0 lies in one patch pixel
-        return mode != 0 || !tmask || ((tmask[m0 >> 7] >> (k0 >> 6)) & 1u);
+    struct Ctx { unsigned tm; int b0; };      // the tile's support union; dense1 row of the group's patch pixel (0,0)
+    __device__ __forceinline__ Ctx wg_ctx(int m0) const {      // gemm_rowk, BM = 128
+        Ctx c{0xFFFFFFFFu, 0};
+        if (mode == 0) {
+            if (tmask) c.tm = tmask[m0 >> 7];
+            const int g = tilegroup[m0 >> 8], oy = g / 3, ox = g - oy * 3;
+            c.b0 = (oy * 7 + ox) * 64;
+        }
+        return c;
+    }
+    __device__ __forceinline__ bool tile_ok_c(const Ctx &c, int k0) const { return (c.tm >> (k0 >> 6)) & 1u; }      // mode 0: K-tile k0 lies in one patch pixel
+    __device__ __forceinline__ int bk_c(const Ctx &c, int k0) const {
+        if (mode != 0) return k0;
+        const int py = k0 / 320;
+        return c.b0 + py * 128 + k0;      // ((oy + py) * 7 + ox) * 64 + (k0 - py * 320)
     }
     __device__ __forceinline__ bool tile_active(int m0) const { return tilegroup[m0 >> 8] >= 0; }
-    __device__ __forceinline__ int bk(int k0, int m0) const {
-        if (mode != 0) return k0;
-        const int g = tilegroup[m0 >> 8], oy = g / 3, ox = g - oy * 3;
-        const int py = k0 / 320, rest = k0 - py * 320;
-        return ((oy + py) * 7 + ox) * 64 + rest;
-    }
     __device__ __forceinline__ int bn(int n0, int m0) const {
         if (mode != 1) return n0;
         const int g = tilegroup[m0 >> 8], oy = g / 3, ox = g - oy * 3;
@@ -724,6 +773,36 @@ struct EpiConv2Corr {
     __device__ __forceinline__ bool bit(float v, float z) const { return v + z > 0.f; }
     __device__ __forceinline__ void store_bits(int, int, unsigned long long w, int slot) const {
         if (slot >= 0) m2[slot] = w;
+    }
+};
+
+// SlotsToPatch's epilogue: v = the agent's correction of conv3's pre-activation at the row's patch pixel; z = the env's shared
+// pre-activation there (z3sh, or the background row where the trunk's list form did not compute it: z offset < 0).  Writes
+// d3 = relu(z + v) - relu(z) and, for pixels of the agent's own support, the 64 sign bits of relu(z + v) (m3) -- what
+// expand_conv3_patch_kernel wrote.  Rows outside the own support have no live tap: v = 0, d3 = 0.
+struct EpiPatchExpand {
+    static constexpr bool kColSum = false, kAddAux = true;
+    static constexpr bool kRowBits = true;
+    // Everything the store pass needs of a row rides in ONE register (its descriptor's code word, fetched in the load pass): a load
+    // behind the first store would wait for it (d3 may alias anything as far as the compiler knows), once per element.
+    //   code = inside << 30 | affected << 29 | map pixel p << 23 | sample m << 5 | patch pixel q; -1: a dead row
+    const int4 *desc;
+    const float *z3sh, *z3bg;
+    float *d3;
+    unsigned long long *m3;
+    __device__ __forceinline__ int row_aux_n(int r, int) const { return desc[r].x; }
+    __device__ __forceinline__ float elem_aux(int, int c, int code) const {
+        if (code < 0) return 0.f;
+        const int m = (code >> 5) & 0x1FFFF, p = (code >> 23) & 63;
+        return ((code >> 29) & 1) ? z3sh[(long)(m / 10) * 3136 + p * 64 + c] : z3bg[c];
+    }
+    __device__ __forceinline__ void store(int, int c, float v, int code, float z) const {
+        if (code < 0) return;
+        d3[(long)((code >> 5) & 0x1FFFF) * 1600 + (code & 31) * 64 + c] = fmaxf(v + z, 0.f) - fmaxf(z, 0.f);
+    }
+    __device__ __forceinline__ bool bit(float v, float z) const { return v + z > 0.f; }
+    __device__ __forceinline__ void store_bits(int, int, unsigned long long w, int code) const {
+        if (code >= 0 && ((code >> 30) & 1)) m3[(long)((code >> 5) & 0x1FFFF) * 25 + (code & 31)] = w;
     }
 };
 
@@ -991,6 +1070,24 @@ __device__ __forceinline__ void mfma_f32_step(const float *__restrict__ Af, cons
 }
 
 // optional hooks of a gather descriptor: whole output column tiles (gemm_rowk) / output row tiles (gemm_tn) known to be zero
+// Per-workgroup context of a gather (wg_ctx): what tile_ok / bk need of the workgroup's tile, loaded ONCE before the K loop.  A
+// load inside the loop is re-issued every iteration (the barriers are fences), and a byte or halfword one is a VECTOR load whose
+// s_waitcnt vmcnt(0) also waits for the tile prefetch issued just before it: the loop then runs at one memory latency per K-tile
+// (measured round 4: dense1's patch forward and the conv3 patch gather).
+template <class T, class = void> struct ag_has_ctx : std::false_type {};
+template <class T> struct ag_has_ctx<T, std::void_t<decltype(std::declval<const T &>().wg_ctx(0))>> : std::true_type {};
+template <class AG> __device__ __forceinline__ auto ag_ctx(const AG &ag, int m0) {
+    if constexpr (ag_has_ctx<AG>::value) return ag.wg_ctx(m0);
+    else return m0;
+}
+template <class AG, class C> __device__ __forceinline__ bool ag_tile_ok(const AG &ag, const C &c, int m0, int k0) {
+    if constexpr (ag_has_ctx<AG>::value) return ag.tile_ok_c(c, k0);
+    else return ag.tile_ok(m0, k0);
+}
+template <class AG, class C> __device__ __forceinline__ int ag_bk(const AG &ag, const C &c, int m0, int k0) {
+    if constexpr (ag_has_ctx<AG>::value) return ag.bk_c(c, k0);
+    else return ag.bk(k0, m0);
+}
 template <class T, class = void> struct ag_has_n_ok : std::false_type {};
 template <class T> struct ag_has_n_ok<T, std::void_t<decltype(std::declval<const T &>().n_ok(0, 0))>> : std::true_type {};
 template <class T, class = void> struct ag_has_i_ok : std::false_type {};
@@ -1035,6 +1132,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void gemm_rowk(AG ag
         if (!ag.n_ok(m0, n0)) return;            // its consumer knows the same masks (agent_dz3_kernel)
     }
     const int M = ag.rows, K = ag.K();
+    const auto wctx = ag_ctx(ag, m0);
     const int trow = tid >> 3, tk4 = (tid & 7) * 4;
     const int wo = (((tk4 >> 3) ^ swz(trow)) << 3) + (tk4 & 4);      // swizzled k offset of this thread's stores (rows trow + RPP i: same swizzle)
 
@@ -1069,7 +1167,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void gemm_rowk(AG ag
             vmask = v ? (vmask | (1u << i)) : (vmask & ~(1u << i));   /* the zero-fill select happens at store time */ \
         }                                                                                                  \
         /* named scalars, not an array: an array here is "promoted" to LDS by the compiler */             \
-        const int bko = ag.bk((kt_) * BK, m0);                                                             \
+        const int bko = ag_bk(ag, wctx, m0, (kt_) * BK);                                                             \
         rb0 = *reinterpret_cast<const float4 *>(brow0 + bko);                                              \
         if (NB > 1) rb1 = *reinterpret_cast<const float4 *>(brow0 + (long)RPP * ldb + bko);                \
         if (NB > 2) rb2 = *reinterpret_cast<const float4 *>(brow0 + (long)2 * RPP * ldb + bko);            \
@@ -1112,7 +1210,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void gemm_rowk(AG ag
     const int nk = K / BK;
     // K-tiles whose tap is outside the image for the WHOLE workgroup are skipped (tile_ok is block-uniform)
     int kt = 0;
-    while (kt < nk && !ag.tile_ok(m0, kt * BK)) ++kt;
+    while (kt < nk && !ag_tile_ok(ag, wctx, m0, kt * BK)) ++kt;
     GRL_LOAD_TILE(kt < nk ? kt : 0)
     // MFMA operand: lane (r = lane & 15, g = lane >> 4) holds k = 8g .. 8g+7 of row r -> one ds_read_b128 per plane
     const int l16 = lane & 15, kg = lane >> 4;
@@ -1123,7 +1221,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void gemm_rowk(AG ag
         GRL_STORE_TILE()
         __syncthreads();
         int ktn = kt + 1;
-        while (ktn < nk && !ag.tile_ok(m0, ktn * BK)) ++ktn;
+        while (ktn < nk && !ag_tile_ok(ag, wctx, m0, ktn * BK)) ++ktn;
         {   // prefetch the next valid K-tile (the last iteration re-reads its own tile: branch-free)
             const int ktl = ktn < nk ? ktn : kt;
             GRL_LOAD_TILE(ktl)

@@ -1,13 +1,14 @@
 # Round 4: per-kernel durations of full PAAC updates at 8 192 envs (one 81 920-sample chunk per step, single stream):
 # rocprofv3 --kernel-trace --stats; prints every kernel above 0.3 %, the GEMM / non-GEMM split and the launches per update.
-# usage: bash tools/kstats_r04.sh TAG [env assignments...]     -> gpurun_out/r4_ks_TAG.csv
+# usage: bash tools/kstats_r04.sh TAG [env assignments | --bench-flags ...]     -> gpurun_out/r4_ks_TAG.csv
 set -e
 TAG=${1:-x}; shift || true
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf gpurun_out/ks_$TAG && mkdir -p gpurun_out
-for kv in "$@"; do export "$kv"; done
+EXTRA=""
+for kv in "$@"; do case "$kv" in --*) EXTRA="$EXTRA $kv";; *) export "$kv";; esac; done
 UPD=3
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ks_$TAG -- python3 bench.py --envs 8192 --steps 2 --warmup 0 --no-cpu-baseline --no-extras --single-stream > gpurun_out/ks_$TAG.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ks_$TAG -- python3 bench.py --envs 8192 --steps 2 --warmup 0 --no-cpu-baseline --no-extras --single-stream $EXTRA > gpurun_out/ks_$TAG.log 2>&1
 python3 - "$TAG" "$UPD" <<'PY'
 import csv, glob, sys
 tag, upd = sys.argv[1], int(sys.argv[2])
