@@ -115,7 +115,7 @@ struct NetLane {
     float *cfold;              // kFoldParts x 32 partial sums of fold_class_sums_kernel
     // conv2 corrections as a GEMM (net_shared.inc): A rows, class sort, canonical-slot maps
     float *carow;
-    int *cperm, *cblkcnt, *cblkoff, *cgoff, *cslot;
+    int *cperm, *cblkcnt, *cblkoff, *cgoff, *cslot, *cinv;
     signed char *ctilegroup;
     double *slab64;
     float *ro_mu;              // chunk-sized scratch of the gradient step (cmu csigma cvs dzh cact cadv cy)
@@ -275,12 +275,12 @@ enum {
 };
 
 // every GEMM launch goes through these two: the net's arithmetic form picks the instantiation
-template <int BM, int BN, int WGM, int WGN, class AG, class Epi, bool XCD = true, bool FENCE = true>
+template <int BM, int BN, int WGM, int WGN, class AG, class Epi, bool XCD = true, bool FENCE = true, int NBUF = 1>
 static void launch_rowk(grl_net *net, dim3 grid, hipStream_t st, AG ag, const float *Bt, int ldb, int N, Epi epi) {
     if (net->gemm_f32)
-        hipLaunchKernelGGL((gemm_rowk<BM, BN, WGM, WGN, AG, Epi, XCD, FENCE, true>), grid, dim3(64 * WGM * WGN), 0, st, ag, Bt, ldb, N, epi);
+        hipLaunchKernelGGL((gemm_rowk<BM, BN, WGM, WGN, AG, Epi, XCD, FENCE, true, NBUF>), grid, dim3(64 * WGM * WGN), 0, st, ag, Bt, ldb, N, epi);
     else
-        hipLaunchKernelGGL((gemm_rowk<BM, BN, WGM, WGN, AG, Epi, XCD, FENCE, false>), grid, dim3(64 * WGM * WGN), 0, st, ag, Bt, ldb, N, epi);
+        hipLaunchKernelGGL((gemm_rowk<BM, BN, WGM, WGN, AG, Epi, XCD, FENCE, false, NBUF>), grid, dim3(64 * WGM * WGN), 0, st, ag, Bt, ldb, N, epi);
 }
 template <int BM, int BN, int WGM, int WGN, class AG, int XCD = 1>
 static void launch_tn(grl_net *net, dim3 grid, hipStream_t st, AG ag, const float *dY, int J, int mc, float *slab) {
@@ -811,7 +811,10 @@ static int alloc_lane_forward(grl_net *n) {
     int rc = GRL_OK;
     auto A = [&](float **p, size_t cnt) { if (rc == GRL_OK) rc = nalloc(n, p, cnt); };
     A(&n->grads, n->ho.total);
-    A(&n->a2, c * 5184); A(&n->d1, c * 512); A(&n->d2, c * 256); A(&n->p1, c * 512); A(&n->v1, c * 512); A(&n->v2, c * 256);
+    // a2: the per-agent conv2 tensor of the dense form; in shared-trunk mode the workspace of conv3's gather form (net_patch.inc:
+    // canonical cell blocks of ctiles * 256 rows, then the items' descriptors, tap masks, tile masks and sort counters)
+    const size_t gather_ws = (size_t)n->ctiles * 256 * 576 + (c * 25 + 256) * 4 + (c * 25 + 1024) + 2 * ((c + 255) / 256 + 1) * 64 + 4096;
+    A(&n->a2, std::max(c * 5184, gather_ws)); A(&n->d1, c * 512); A(&n->d2, c * 256); A(&n->p1, c * 512); A(&n->v1, c * 512); A(&n->v2, c * 256);
     if (!n->shared_trunk) { A(&n->a1, c * 12800); A(&n->a3, c * 3136); }       // per-agent tensors the shared evaluation never forms
     A(&n->sraw, (c / 10) * 12800); A(&n->z2sh, (c / 10) * 5184);
     A(&n->a2sh, (c / 10) * 5184); A(&n->d2s, c * 9 * 64); if (rc == GRL_OK) rc = nalloc(n, &n->m2s, c * 9); A(&n->z3sh, (c / 10) * 3136);
@@ -875,6 +878,7 @@ static int alloc_lane_forward(grl_net *n) {
     if (rc == GRL_OK) rc = nalloc(n, &n->cblkoff, ((c + 255) / 256) * 4);
     if (rc == GRL_OK) rc = nalloc(n, &n->cgoff, 8);
     if (rc == GRL_OK) rc = nalloc(n, &n->cslot, c * 9);
+    if (rc == GRL_OK) rc = nalloc(n, &n->cinv, c);
     if (rc == GRL_OK) rc = nalloc(n, &n->ctilegroup, (size_t)n->ctiles);
     if (rc == GRL_OK) {
         grl_net *net = n;

@@ -519,7 +519,7 @@ struct SlotGatherT3P {
 // through memory per chunk.
 struct SlotsToPatch {
     static constexpr bool kRelu = false;
-    const float *base;               // d2c
+    const float *base;               // d2c: canonical cell blocks in the row order of the conv2 correction GEMM (EpiConv2Corr)
     const int4 *desc;                // per sorted row: {code (EpiPatchExpand), element offset of tap (0,0) in d2c, live kernel rows << 3 | columns, spare}
     int rows;                        // upper bound (25 per sample); the live count is *rows_dev
     const int *rows_dev;
@@ -762,13 +762,19 @@ struct EpiConv2Corr {
     float *d2;
     unsigned long long *m2;
     const int *perm, *cslot;
+    // second copy for conv3's gather form (SlotsToPatch): the output tile as it is, d2c[sorted row][canonical cell][64] -- cells the
+    // agent does not have are not written (and never gathered).  nullptr: the slot-product form of conv3's corrections
+    float *d2c;
     __device__ __forceinline__ int row_aux_n(int r, int colbase) const {
         const int m = perm[r];
         return m < 0 ? -1 : cslot[m * 9 + (colbase >> 6)];
     }
     __device__ __forceinline__ float elem_aux(int, int c, int slot) const { return slot >= 0 ? d2[(long)slot * 64 + (c & 63)] : 0.f; }
-    __device__ __forceinline__ void store(int, int c, float v, int slot, float z) const {
-        if (slot >= 0) d2[(long)slot * 64 + (c & 63)] = fmaxf(v + z, 0.f) - fmaxf(z, 0.f);
+    __device__ __forceinline__ void store(int r, int c, float v, int slot, float z) const {
+        if (slot < 0) return;
+        const float d = fmaxf(v + z, 0.f) - fmaxf(z, 0.f);
+        d2[(long)slot * 64 + (c & 63)] = d;
+        if (d2c) d2c[(long)r * 576 + c] = d;
     }
     __device__ __forceinline__ bool bit(float v, float z) const { return v + z > 0.f; }
     __device__ __forceinline__ void store_bits(int, int, unsigned long long w, int slot) const {
@@ -1099,15 +1105,21 @@ template <class T> struct ag_has_i_ok<T, std::void_t<decltype(std::declval<const
 // loop waits on its loads and barriers more than on the matrix pipe, and more resident waves cover those waits (+4-18 % on the
 // dense1 shapes, most on short K: tools/ubench/gemm_f16x3.hip).  The second launch bound is waves per SIMD (HIP-Clang): two
 // workgroups per CU either way, i.e. a 256- or 128-register budget.
-template <int BM, int BN, int WGM, int WGN, class AG, class Epi, bool XCD_ORDER = true, bool FENCE = true, bool F32 = false>
+template <int BM, int BN, int WGM, int WGN, class AG, class Epi, bool XCD_ORDER = true, bool FENCE = true, bool F32 = false, int NBUF = 1>
 __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void gemm_rowk(AG ag, const float *__restrict__ Bt, int ldb, int N, Epi epi) {
     constexpr int BK = 32, LDH = kLdh, NT = 64 * WGM * WGN, RPP = NT / 8;          // RPP: tile rows staged per pass (8 threads per row)
     constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 16, TN = WN / 16;       // 16x16 MFMA tiles per wave
     constexpr int NA = BM / RPP;                      // float4 per thread for the A tile
     constexpr int NB = BN / RPP;                      // float4 per thread for the B tile
     static_assert((WGM * WGN == 4 || WGM * WGN == 8) && TM >= 1 && TN >= 1 && NA >= 1 && BN % RPP == 0, "4 or 8 waves");
-    __shared__ __attribute__((aligned(16))) unsigned short As[2][BM * LDH];      // planes h, l'
-    __shared__ __attribute__((aligned(16))) unsigned short Bs[2][BN * LDH];
+    // NBUF = 2: tile k+1 is staged into the other LDS buffer while tile k is multiplied, one barrier per K-tile instead of two (staging
+    // and the fragment reads of one iteration touch different buffers).  Per instance, measured in the product (round 4, 81 920-sample
+    // chunk): the paired small-dense data gradient -11 %, dense1's per-env forward under the union mask -7 %, dense1's patch forward
+    // -4 %; the 256 x 64 patch data gradient +9 %, the conv3 trunk list forward +7 %, every other instance within +-2.5 % -- so three
+    // instances use it (tools/ubench/gemm_f16x3.hip had found -2.5 ... +5 % on the dense shapes).
+    static_assert(NBUF == 1 || NBUF == 2, "one or two LDS buffers");
+    __shared__ __attribute__((aligned(16))) unsigned short As[NBUF][2][BM * LDH];      // planes h, l'
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[NBUF][2][BN * LDH];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave - wm * WGN;
@@ -1184,19 +1196,19 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void gemm_rowk(AG ag
             *reinterpret_cast<uint2 *>(&S_[1][(row_) * LDH + wo]) = l_;                                    \
         }                                                                                                  \
     }
-#define GRL_STORE_TILE()                                                                                   \
+#define GRL_STORE_TILE(buf_)                                                                               \
     {                                                                                                      \
         _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                   \
             const bool v = (vmask >> i) & 1u;                                                              \
             float4 t4 = ra[i];                                                                             \
             t4.x = v ? t4.x : 0.f; t4.y = v ? t4.y : 0.f; t4.z = v ? t4.z : 0.f; t4.w = v ? t4.w : 0.f;    \
             if (AG::kRelu) { t4.x = fmaxf(t4.x, 0.f); t4.y = fmaxf(t4.y, 0.f); t4.z = fmaxf(t4.z, 0.f); t4.w = fmaxf(t4.w, 0.f); } \
-            GRL_STORE_PLANES(As, trow + RPP * i, t4)                                                       \
+            GRL_STORE_PLANES(As[buf_], trow + RPP * i, t4)                                                 \
         }                                                                                                  \
-        GRL_STORE_PLANES(Bs, trow, rb0)                                                                    \
-        if (NB > 1) GRL_STORE_PLANES(Bs, trow + RPP, rb1)                                                  \
-        if (NB > 2) GRL_STORE_PLANES(Bs, trow + 2 * RPP, rb2)                                              \
-        if (NB > 2) GRL_STORE_PLANES(Bs, trow + 3 * RPP, rb3)                                              \
+        GRL_STORE_PLANES(Bs[buf_], trow, rb0)                                                              \
+        if (NB > 1) GRL_STORE_PLANES(Bs[buf_], trow + RPP, rb1)                                            \
+        if (NB > 2) GRL_STORE_PLANES(Bs[buf_], trow + 2 * RPP, rb2)                                        \
+        if (NB > 2) GRL_STORE_PLANES(Bs[buf_], trow + 3 * RPP, rb3)                                        \
     }
 
     f32x4 acc[TM][TN], acl[TM][TN];
@@ -1217,54 +1229,79 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void gemm_rowk(AG ag
     const int ro = (kg ^ swz(l16)) << 3;
     const int aro = (wm * WM + l16) * LDH + ro;
     const int bro = (wn * WN + l16) * LDH + ro;
-    while (kt < nk) {
-        GRL_STORE_TILE()
-        __syncthreads();
-        int ktn = kt + 1;
-        while (ktn < nk && !ag_tile_ok(ag, wctx, m0, ktn * BK)) ++ktn;
-        {   // prefetch the next valid K-tile (the last iteration re-reads its own tile: branch-free)
-            const int ktl = ktn < nk ? ktn : kt;
-            GRL_LOAD_TILE(ktl)
-        }
-        if constexpr (FENCE) { GRL_SCHED_FENCE }
-        {   // one K = 32 step per tile
-            if constexpr (F32) {
-                mfma_f32_step<TM, TN>(reinterpret_cast<const float *>(&As[0][0]), reinterpret_cast<const float *>(&Bs[0][0]), wm * WM + l16,
-                                      wn * WN + l16, kg, acc);
-            } else if constexpr (TM < TN) {      // keep the smaller operand's fragments live, stream the other one (fewer registers)
-                f16x8 af[TM][2];
-#pragma unroll
-                for (int a = 0; a < TM; ++a)
-#pragma unroll
-                    for (int p = 0; p < 2; ++p) af[a][p] = *reinterpret_cast<const f16x8 *>(&As[p][aro + a * 16 * LDH]);
-#pragma unroll
-                for (int b = 0; b < TN; ++b) {
-                    f16x8 bf[2];
-#pragma unroll
-                    for (int p = 0; p < 2; ++p) bf[p] = *reinterpret_cast<const f16x8 *>(&Bs[p][bro + b * 16 * LDH]);
-#pragma unroll
-                    for (int a = 0; a < TM; ++a) mfma_x3(acc[a][b], acl[a][b], af[a], bf);
-                }
-            } else {
-                f16x8 bf[TN][2];
-#pragma unroll
-                for (int b = 0; b < TN; ++b)
-#pragma unroll
-                    for (int p = 0; p < 2; ++p) bf[b][p] = *reinterpret_cast<const f16x8 *>(&Bs[p][bro + b * 16 * LDH]);
-#pragma unroll
-                for (int a = 0; a < TM; ++a) {
-                    f16x8 af[2];
-#pragma unroll
-                    for (int p = 0; p < 2; ++p) af[p] = *reinterpret_cast<const f16x8 *>(&As[p][aro + a * 16 * LDH]);
-#pragma unroll
-                    for (int b = 0; b < TN; ++b) mfma_x3(acc[a][b], acl[a][b], af, bf[b]);
-                }
-            }
-        }
-        if constexpr (FENCE) { GRL_SCHED_FENCE }
-        __syncthreads();
-        kt = ktn;
+    // one K = 32 step on the tile in LDS buffer cb_
+#define GRL_MFMA_TILE(cb_)                                                                                                             \
+    {                                                                                                                                  \
+        if constexpr (F32) {                                                                                                           \
+            mfma_f32_step<TM, TN>(reinterpret_cast<const float *>(&As[cb_][0][0]), reinterpret_cast<const float *>(&Bs[cb_][0][0]),    \
+                                  wm * WM + l16, wn * WN + l16, kg, acc);                                                              \
+        } else if constexpr (TM < TN) { /* keep the smaller operand's fragments live, stream the other one (fewer registers) */        \
+            f16x8 af[TM][2];                                                                                                           \
+            _Pragma("unroll") for (int a = 0; a < TM; ++a)                                                                             \
+                _Pragma("unroll") for (int p = 0; p < 2; ++p) af[a][p] = *reinterpret_cast<const f16x8 *>(&As[cb_][p][aro + a * 16 * LDH]); \
+            _Pragma("unroll") for (int b = 0; b < TN; ++b) {                                                                           \
+                f16x8 bf[2];                                                                                                           \
+                _Pragma("unroll") for (int p = 0; p < 2; ++p) bf[p] = *reinterpret_cast<const f16x8 *>(&Bs[cb_][p][bro + b * 16 * LDH]); \
+                _Pragma("unroll") for (int a = 0; a < TM; ++a) mfma_x3(acc[a][b], acl[a][b], af[a], bf);                               \
+            }                                                                                                                          \
+        } else {                                                                                                                       \
+            f16x8 bf[TN][2];                                                                                                           \
+            _Pragma("unroll") for (int b = 0; b < TN; ++b)                                                                             \
+                _Pragma("unroll") for (int p = 0; p < 2; ++p) bf[b][p] = *reinterpret_cast<const f16x8 *>(&Bs[cb_][p][bro + b * 16 * LDH]); \
+            _Pragma("unroll") for (int a = 0; a < TM; ++a) {                                                                           \
+                f16x8 af[2];                                                                                                           \
+                _Pragma("unroll") for (int p = 0; p < 2; ++p) af[p] = *reinterpret_cast<const f16x8 *>(&As[cb_][p][aro + a * 16 * LDH]); \
+                _Pragma("unroll") for (int b = 0; b < TN; ++b) mfma_x3(acc[a][b], acl[a][b], af, bf[b]);                               \
+            }                                                                                                                          \
+        }                                                                                                                              \
     }
+    if constexpr (NBUF == 1) {
+        while (kt < nk) {
+            GRL_STORE_TILE(0)
+            __syncthreads();
+            int ktn = kt + 1;
+            while (ktn < nk && !ag_tile_ok(ag, wctx, m0, ktn * BK)) ++ktn;
+            {   // prefetch the next valid K-tile (the last iteration re-reads its own tile: branch-free)
+                const int ktl = ktn < nk ? ktn : kt;
+                GRL_LOAD_TILE(ktl)
+            }
+            if constexpr (FENCE) { GRL_SCHED_FENCE }
+            GRL_MFMA_TILE(0)
+            if constexpr (FENCE) { GRL_SCHED_FENCE }
+            __syncthreads();
+            kt = ktn;
+        }
+    } else {
+        // tile kt is in buffer cb, tile ktn in the registers (loads in flight); an iteration stages ktn into the other buffer, starts
+        // the loads of the tile after it and multiplies tile kt.  The barrier at its end covers both hazards: the staged tile is
+        // complete before anyone reads it, and everyone has read buffer cb before the next iteration stages over it.
+        int ktn = nk;
+        if (kt < nk) {
+            GRL_STORE_TILE(0)
+            ktn = kt + 1;
+            while (ktn < nk && !ag_tile_ok(ag, wctx, m0, ktn * BK)) ++ktn;
+            GRL_LOAD_TILE(ktn < nk ? ktn : kt)
+            __syncthreads();
+        }
+        int cb = 0;
+        while (kt < nk) {
+            int ktnn = ktn;
+            if (ktn < nk) {      // block-uniform
+                GRL_STORE_TILE(cb ^ 1)
+                ktnn = ktn + 1;
+                while (ktnn < nk && !ag_tile_ok(ag, wctx, m0, ktnn * BK)) ++ktnn;
+                GRL_LOAD_TILE(ktnn < nk ? ktnn : ktn)
+            }
+            if constexpr (FENCE) { GRL_SCHED_FENCE }
+            GRL_MFMA_TILE(cb)
+            if constexpr (FENCE) { GRL_SCHED_FENCE }
+            __syncthreads();
+            kt = ktn;
+            ktn = ktnn;
+            cb ^= 1;
+        }
+    }
+#undef GRL_MFMA_TILE
     // the cross terms carry 2^11
     if constexpr (!F32) {
 #pragma unroll
