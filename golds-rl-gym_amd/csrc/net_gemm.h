@@ -1104,7 +1104,9 @@ template <class T> struct ag_has_i_ok<T, std::void_t<decltype(std::declval<const
 // (32 x 64: 64 accumulator registers instead of 128), so four waves fit a SIMD instead of two: with three MFMAs per product the
 // loop waits on its loads and barriers more than on the matrix pipe, and more resident waves cover those waits (+4-18 % on the
 // dense1 shapes, most on short K: tools/ubench/gemm_f16x3.hip).  The second launch bound is waves per SIMD (HIP-Clang): two
-// workgroups per CU either way, i.e. a 256- or 128-register budget.
+// workgroups per CU either way, i.e. a 256- or 128-register budget.  (Round 4: the 128 x 64 four-wave instances sit at 134-150 registers,
+// three waves per SIMD; capped at 128 they spill 8-92 bytes per lane and the conv3 patch gather went 125 -> 193 us, conv2's class
+// corrections 113 -> 151, the conv3 row-list data gradient 62 -> 80 -- not adopted.)
 template <int BM, int BN, int WGM, int WGN, class AG, class Epi, bool XCD_ORDER = true, bool FENCE = true, bool F32 = false, int NBUF = 1>
 __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void gemm_rowk(AG ag, const float *__restrict__ Bt, int ldb, int N, Epi epi) {
     constexpr int BK = 32, LDH = kLdh, NT = 64 * WGM * WGN, RPP = NT / 8;          // RPP: tile rows staged per pass (8 threads per row)

@@ -36,7 +36,7 @@ def family(k):
     tn = k.startswith("void grl::gemm_tn")
     if "PatchRows" in k:
         return "dense1_patch_wgrad" if tn else ("dense1_patch_fwd" if "EpiPatchFwd" in k else "dense1_patch_dgrad")
-    if "SlotRowsP" in k:
+    if "SlotRowsP" in k or "SlotsToPatch" in k:      # conv3's per-agent corrections: slot products (GRL_NET_EXPAND3=prod) or the patch gather
         return "slot_products_fwd"
     if "SlotGatherT3P" in k:
         return "slot_wgrad" if tn else "slot_dgrad"
