@@ -622,6 +622,48 @@ def test_patch_support_masks_change_nothing_but_the_work(monkeypatch):
     eng.close()
 
 
+def test_the_two_forms_of_conv3s_per_agent_corrections_agree(monkeypatch):
+    """conv3's per-agent corrections are one gather GEMM at the agents' patch pixels (net_gemm.h SlotsToPatch, rows sorted by their set
+    of live taps); GRL_NET_EXPAND3=prod keeps the earlier form (slot products + expansion kernel).  Both add the same terms -- in a
+    different order: one accumulator over the 576-long reduction against a sum of nine 64-long products -- so heads and gradients
+    agree at the float32 level, not bitwise.  Border and corner agents (one to nine live cells), ragged chunks, several tiles per tap
+    class."""
+    from goldsrl import _ffi, _ffi_net
+    E = 120
+    eng = _ffi.Engine(_ffi.ENV_SWARM, E, seed=3)
+    eng.reset()
+    rng = np.random.RandomState(15)
+    edge = [0, 1, 2, 3, 5, 8, 75, 79, 80, 82, 83]
+    lb = rng.randint(0, 84, size=(E, 80, 2)).astype(np.uint8)
+    pos = np.zeros((E, 10, 2), np.uint8)
+    for e in range(E):
+        for a in range(10):
+            kind = (a + e) % 4
+            pos[e, a] = ((rng.choice(edge), rng.choice(edge)) if kind == 0 else (rng.randint(0, 84), rng.choice(edge)) if kind == 1
+                         else (rng.choice(edge), rng.randint(0, 84)) if kind == 2 else (rng.randint(0, 84), rng.randint(0, 84)))
+    ab = pos.copy()
+    act, adv, y = _train_inputs(E, seed=16)
+    flat = _ffi_net.glorot_uniform_flat(seed=17)
+    res = {}
+    for mode in ("gather", "prod"):
+        monkeypatch.setenv("GRL_NET_EXPAND3", mode)      # read when the net is created
+        net = _ffi_net.ConvNet(eng, max_chunk_samples=500)
+        net.set_params(flat)
+        out = net.predict_obs(lb, ab, pos)
+        net.train_obs(lb, ab, pos, act, adv, y, lr=0.0, apply_update=False)
+        res[mode] = (out, net.get_grads().copy())
+        net.close()
+    for k in ("mu", "sigma", "vs"):
+        np.testing.assert_allclose(res["gather"][0][k], res["prod"][0][k], rtol=2e-6, atol=2e-7, err_msg=k)
+    g, h = res["gather"][1], res["prod"][1]
+    assert np.isfinite(g).all() and not np.array_equal(g, h)      # two different kernels did run
+    gb, hb = NN.unflatten_params(g.astype(np.float64)), NN.unflatten_params(h.astype(np.float64))
+    for name in hb:
+        tol = 2e-5 * max(np.abs(hb[name]).max(), 1e-30)
+        assert np.abs(gb[name] - hb[name]).max() <= tol, name
+    eng.close()
+
+
 @pytest.mark.parametrize("layout", ["mixed", "strip"])
 def test_trunk_row_lists_change_nothing_but_the_work(monkeypatch, layout):
     """The env's shared trunk is mostly background: conv1 pixels no bin touches hold b1, conv2 outputs whose window sees none of the
