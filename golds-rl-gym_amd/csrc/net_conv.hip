@@ -435,9 +435,12 @@ __global__ __launch_bounds__(256) void conv1_sparse_kernel(const uint8_t *__rest
 // the union of its pixels' non-zero taps with 4 of 64 lanes busy per step, ~110 of the kernel's 152 us per 8 192-env chunk; and
 // the count / 80 division sat on that path too -- now tabulated.)  Same sums in the same order as conv1_sparse_kernel
 // (bit-identical output).  nmask (list form of the trunk): the 2 x 2 pixel blocks anybody reads; the rest is not written.
+// Round 4: one resident wave of workgroups strides over the envs: the 16 KB of weights, the two value tables and the zeroed count
+// grids are set up once per workgroup, an env's <= 90 increments are taken back after its walk (instead of zeroing 14 KB per env),
+// and the next env's bins are fetched while the current one is walked.
 __global__ __launch_bounds__(256) void conv1_sparse_shared_kernel(const uint8_t *__restrict__ lbins, const uint8_t *__restrict__ abins,
                                                                   const float *__restrict__ w1, const float *__restrict__ b1, int G,
-                                                                  float *__restrict__ sraw, const unsigned *__restrict__ nmask) {
+                                                                  float *__restrict__ sraw, const unsigned *__restrict__ nmask, int nenv) {
     __shared__ unsigned int cnt[2][7056 / 4 + 4];   // 84x84 byte counters per channel, packed 4 per word
     __shared__ unsigned need[4], pm[13];            // blocks anybody reads (nmask == nullptr: all); touched pixels
     __shared__ float vtab[2][96];                   // count / 80, count / 10 as the reference forms them (float64 division rounded to float32, state_processors.py:33)
@@ -445,22 +448,38 @@ __global__ __launch_bounds__(256) void conv1_sparse_shared_kernel(const uint8_t 
     __shared__ unsigned short evl[8][128];          // per half wave: the non-zero taps of its pixel, in order
     __shared__ int ntouched;
     // the two count channels' kernels [tap][c][co]: with the weights in global memory every step of the walk below was a dependent
-    // cache round trip
+    // cache round trip.  (Keeping only the locust channel's 8 KB here -- six workgroups per CU instead of four -- measured 101 against
+    // 100 us: occupancy is not what binds this kernel.)
     __shared__ __attribute__((aligned(16))) float wl[64 * 2 * 32];
-    const int env = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     for (int i = tid; i < 64 * 2 * 8; i += 256) {
         const int t = i >> 4, c = (i >> 3) & 1, j = i & 7;
         reinterpret_cast<float4 *>(wl)[i] = *reinterpret_cast<const float4 *>(w1 + (t * 3 + c) * 32 + j * 4);
     }
-    if (tid < 4) need[tid] = nmask ? nmask[(size_t)env * 4 + tid] : 0xFFFFFFFFu;
-    if (tid >= 32 && tid < 45) pm[tid - 32] = 0;
     if (tid >= 64 && tid < 64 + 81) vtab[0][tid - 64] = (float)((double)(tid - 64) / 80.0);
     if (tid >= 160 && tid < 160 + 11) vtab[1][tid - 160] = (float)((double)(tid - 160) / 10.0);
     for (int i = tid; i < 2 * (7056 / 4 + 4); i += 256) (&cnt[0][0])[i] = 0;
+    // this lane's bin of the first env; inside the loop: of the next one
+    int nbx = 255, nby = 0;
+    unsigned nneed = 0xFFFFFFFFu;
+    auto fetch = [&](int e) {
+        if (e < nenv) {
+            if (tid < 90) {
+                const uint8_t *q = tid < 80 ? lbins + ((size_t)e * 80 + tid) * 2 : abins + ((size_t)e * 10 + (tid - 80)) * 2;
+                nbx = q[0]; nby = q[1];
+            }
+            if (tid < 4 && nmask) nneed = nmask[(size_t)e * 4 + tid];
+        }
+    };
+    fetch(blockIdx.x);
+  for (int env = blockIdx.x; env < nenv; env += gridDim.x) {
+    const int bx = nbx, by = nby;
+    __syncthreads();      // the previous env's walk is over (evl, plist, pm, need); its increments are taken back
+    if (tid < 4) need[tid] = nmask ? nneed : 0xFFFFFFFFu;
+    if (tid >= 32 && tid < 45) pm[tid - 32] = 0;
+    fetch(env + gridDim.x);
     __syncthreads();
     if (tid < 90) {
-        const uint8_t *b = tid < 80 ? lbins + ((size_t)env * 80 + tid) * 2 : abins + ((size_t)env * 10 + (tid - 80)) * 2;
-        const int bx = b[0], by = b[1];
         if (bx != 255) {
             const int idx = bx * G + by;
             atomicAdd(&cnt[tid < 80 ? 0 : 1][idx >> 2], 1u << (8 * (idx & 3)));
@@ -523,6 +542,12 @@ __global__ __launch_bounds__(256) void conv1_sparse_shared_kernel(const uint8_t 
         }
         if (live) sraw[(size_t)env * 12800 + pix * 32 + co] = acc;
     }
+    __syncthreads();      // every half wave has read its windows
+    if (tid < 90 && bx != 255) {
+        const int idx = bx * G + by;
+        cnt[tid < 80 ? 0 : 1][idx >> 2] = 0u;      // several bins of a word all write the same zero
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------ heads
