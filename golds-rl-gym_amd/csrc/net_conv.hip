@@ -154,6 +154,7 @@ struct grl_net : NetLane {
     int patch_skip;            // 1: the dense1 patch GEMMs skip what the support masks say is zero (GRL_PATCH_SKIP=off: the plain 5x5 patch)
     int gemm_f32, range_fallback_on, range_fallbacks, range_bits_last, update_skipped_last;
     int loss_scale_on;         // per-pass power-of-two scale of the head gradients (net_train.inc); GRL_NET_LOSS_SCALE=off disables it
+    int acc1;                  // gemm_rowk instances built with ACC1 use it (GRL_NET_ACC1=off: the two-accumulator form everywhere)
     int expand3_gather;        // conv3's per-agent corrections as a gather GEMM at the patch pixels (default; GRL_NET_EXPAND3=prod: slot products + expansion kernel)
     int expand2_gemm, ctiles;  // conv2's per-agent corrections as a class-sorted GEMM (default) or the LDS-resident kernel (GRL_NET_EXPAND2=lds)
     float *w2corr;             // [4 classes][576][128] kernel slices of that GEMM, rebuilt with the transposes
@@ -275,12 +276,22 @@ enum {
 };
 
 // every GEMM launch goes through these two: the net's arithmetic form picks the instantiation
-template <int BM, int BN, int WGM, int WGN, class AG, class Epi, bool XCD = true, bool FENCE = true, int NBUF = 1>
+template <int BM, int BN, int WGM, int WGN, class AG, class Epi, bool XCD = true, bool FENCE = true, int NBUF = 1, bool ACC1 = false>
 static void launch_rowk(grl_net *net, dim3 grid, hipStream_t st, AG ag, const float *Bt, int ldb, int N, Epi epi) {
+    // ACC1, the one-accumulator form (net_gemm.h), buys a workgroup per CU without spilling on the eight-wave 128 x 128 tiles (92-98 -> 78
+    // registers, six waves per SIMD) and the four-wave tiles of <= 128 x 64 (134-150 -> 94-116, four or five instead of three); the
+    // eight-wave 256 x 64 instances spill 16-96 bytes at the 80 registers a third workgroup needs, the four-wave 64 x 64-per-wave tiles
+    // 320.  Measured on every instance it fits (round 4, per 81 920-sample chunk): pol1 + v1 190 -> 173 us, conv2's class corrections
+    // 113 -> 102, the conv3 patch gather 124 -> 120 (interior 390 -> 379); the other dense forwards / data gradients -2 ... -3 %; the
+    // NBUF = 2 instances +3 ... +7 % (80 KB of LDS), EpiGradSum +29 % (44 bytes of scratch) -- so the three that gain use it.  (It also
+    // changes the rounding of a sum, so the two forms of a layer that a test compares bit for bit must agree on it.)
+    constexpr bool kAcc1 = ACC1 && ((WGM * WGN == 8 && BM == 128 && BN == 128) || (WGM * WGN == 4 && BM * BN <= 128 * 64));
     if (net->gemm_f32)
-        hipLaunchKernelGGL((gemm_rowk<BM, BN, WGM, WGN, AG, Epi, XCD, FENCE, true, NBUF>), grid, dim3(64 * WGM * WGN), 0, st, ag, Bt, ldb, N, epi);
+        hipLaunchKernelGGL((gemm_rowk<BM, BN, WGM, WGN, AG, Epi, XCD, FENCE, true, NBUF, false>), grid, dim3(64 * WGM * WGN), 0, st, ag, Bt, ldb, N, epi);
+    else if (kAcc1 && net->acc1)
+        hipLaunchKernelGGL((gemm_rowk<BM, BN, WGM, WGN, AG, Epi, XCD, FENCE, false, NBUF, kAcc1>), grid, dim3(64 * WGM * WGN), 0, st, ag, Bt, ldb, N, epi);
     else
-        hipLaunchKernelGGL((gemm_rowk<BM, BN, WGM, WGN, AG, Epi, XCD, FENCE, false, NBUF>), grid, dim3(64 * WGM * WGN), 0, st, ag, Bt, ldb, N, epi);
+        hipLaunchKernelGGL((gemm_rowk<BM, BN, WGM, WGN, AG, Epi, XCD, FENCE, false, NBUF, false>), grid, dim3(64 * WGM * WGN), 0, st, ag, Bt, ldb, N, epi);
 }
 template <int BM, int BN, int WGM, int WGN, class AG, int XCD = 1>
 static void launch_tn(grl_net *net, dim3 grid, hipStream_t st, AG ag, const float *dY, int J, int mc, float *slab) {
@@ -800,7 +811,7 @@ static int forward_chunk(grl_net *net, const uint8_t *lb, const uint8_t *ab, con
         DenseRows g{net->d2, n, 256, 256};
         GemmTimer t(net, 2.0 * n * 256 * 1024);
         EpiBiasActSplit e{net->p1, net->v1, 512, 512, P + ConvOffsets::p1b, P + net->ho.v1b, net->mb_v1, 8};
-        launch_rowk<128, 128, kW128M, kW128N, DenseRows, EpiBiasActSplit>(net, dim3(1024 / 128, (n + 127) / 128), st, g, net->wpvT, 256, 1024, e);
+        launch_rowk<128, 128, kW128M, kW128N, DenseRows, EpiBiasActSplit, true, true, 1, true>(net, dim3(1024 / 128, (n + 127) / 128), st, g, net->wpvT, 256, 1024, e);
     }
     dense(net->v1, 512, PT + net->ho.v2w, P + net->ho.v2b, 256, net->v2, nullptr);
     }
@@ -995,7 +1006,8 @@ int grl_net_create(grl_handle *h, const grl_net_config *cfg, grl_net **out) {
         n->pfrac[0] = n->pfrac[1] = n->pfrac[2] = 1.0; n->sfrac = 1.0;
         const char *e2 = getenv("GRL_NET_EXPAND2");
         n->expand2_gemm = (e2 && strcmp(e2, "lds") == 0) ? 0 : 1;
-        { const char *e3 = getenv("GRL_NET_EXPAND3"); n->expand3_gather = (e3 && strcmp(e3, "prod") == 0) ? 0 : 1; }
+        { const char *e3 = getenv("GRL_NET_EXPAND3"); n->expand3_gather = (e3 && strcmp(e3, "prod") == 0) ? 0 : 1;
+          const char *a1 = getenv("GRL_NET_ACC1"); n->acc1 = (a1 && strcmp(a1, "off") == 0) ? 0 : 1; }
     }
     n->pslice_rows = PATCH_SLICE_ROWS; n->pwgrad_xcd = 1;      // a row slice per XCD: A and B of a slice fetched once (under the support masks and the lighter traffic of round 3 this order wins by 0.7 %; 2 was the choice for the plain patch)
     if (const char *e = getenv("GRL_PATCH_SLICE")) { const int v = atoi(e); if (v == 256 || v == 512 || v == 1024 || v == 2048 || v == 4096 || v == 8192) n->pslice_rows = v; }

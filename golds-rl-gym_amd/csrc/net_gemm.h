@@ -1107,8 +1107,8 @@ template <class T> struct ag_has_i_ok<T, std::void_t<decltype(std::declval<const
 // workgroups per CU either way, i.e. a 256- or 128-register budget.  (Round 4: the 128 x 64 four-wave instances sit at 134-150 registers,
 // three waves per SIMD; capped at 128 they spill 8-92 bytes per lane and the conv3 patch gather went 125 -> 193 us, conv2's class
 // corrections 113 -> 151, the conv3 row-list data gradient 62 -> 80 -- not adopted.)
-template <int BM, int BN, int WGM, int WGN, class AG, class Epi, bool XCD_ORDER = true, bool FENCE = true, bool F32 = false, int NBUF = 1>
-__global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void gemm_rowk(AG ag, const float *__restrict__ Bt, int ldb, int N, Epi epi) {
+template <int BM, int BN, int WGM, int WGN, class AG, class Epi, bool XCD_ORDER = true, bool FENCE = true, bool F32 = false, int NBUF = 1, bool ACC1 = false>
+__global__ __launch_bounds__(64 * WGM * WGN, ACC1 ? (WGM * WGN == 8 ? 6 : 4) : WGM * WGN / 2) void gemm_rowk(AG ag, const float *__restrict__ Bt, int ldb, int N, Epi epi) {
     constexpr int BK = 32, LDH = kLdh, NT = 64 * WGM * WGN, RPP = NT / 8;          // RPP: tile rows staged per pass (8 threads per row)
     constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 16, TN = WN / 16;       // 16x16 MFMA tiles per wave
     constexpr int NA = BM / RPP;                      // float4 per thread for the A tile
@@ -1121,7 +1121,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void gemm_rowk(AG ag
     // instances use it (tools/ubench/gemm_f16x3.hip had found -2.5 ... +5 % on the dense shapes).
     static_assert(NBUF == 1 || NBUF == 2, "one or two LDS buffers");
     __shared__ __attribute__((aligned(16))) unsigned short As[NBUF][2][BM * LDH];      // planes h, l'
-    __shared__ __attribute__((aligned(16))) unsigned short Bs[NBUF][2][BN * LDH];
+    // ACC1: ONE accumulator set instead of two.  B is the weight operand of every gemm_rowk launch: a third plane holds h_b * 2^11 (exact
+    // in fp16 while |b| < 32; beyond that it is inf, the tile's outputs are inf / NaN, the range guard fires and the net moves to the
+    // fp32 form), so that h_a h_b 2^11 + l'_a h_b + h_a l'_b is one sum carrying 2^11: half the accumulator registers, a third
+    // workgroup per CU.
+    static_assert(!(ACC1 && F32), "the fp32 form has one accumulator set anyway");
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[NBUF][ACC1 ? 3 : 2][BN * LDH];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave - wm * WGN;
@@ -1198,6 +1203,17 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void gemm_rowk(AG ag
             *reinterpret_cast<uint2 *>(&S_[1][(row_) * LDH + wo]) = l_;                                    \
         }                                                                                                  \
     }
+#define GRL_STORE_PLANES_B(S_, row_, v4_)                                                                  \
+    {                                                                                                      \
+        GRL_STORE_PLANES(S_, row_, v4_)                                                                    \
+        if constexpr (ACC1) {                                                                              \
+            uint2 h_, l_;                                                                                  \
+            split4((v4_).x, (v4_).y, (v4_).z, (v4_).w, h_, l_);      /* (the compiler shares it with the one above) */ \
+            const f16x2 k_ = {(_Float16)kLowScale, (_Float16)kLowScale};                                   \
+            const f16x2 s0_ = __builtin_bit_cast(f16x2, h_.x) * k_, s1_ = __builtin_bit_cast(f16x2, h_.y) * k_; \
+            *reinterpret_cast<uint2 *>(&S_[2][(row_) * LDH + wo]) = make_uint2(__builtin_bit_cast(unsigned, s0_), __builtin_bit_cast(unsigned, s1_)); \
+        }                                                                                                  \
+    }
 #define GRL_STORE_TILE(buf_)                                                                               \
     {                                                                                                      \
         _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                   \
@@ -1207,19 +1223,22 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void gemm_rowk(AG ag
             if (AG::kRelu) { t4.x = fmaxf(t4.x, 0.f); t4.y = fmaxf(t4.y, 0.f); t4.z = fmaxf(t4.z, 0.f); t4.w = fmaxf(t4.w, 0.f); } \
             GRL_STORE_PLANES(As[buf_], trow + RPP * i, t4)                                                 \
         }                                                                                                  \
-        GRL_STORE_PLANES(Bs[buf_], trow, rb0)                                                              \
-        if (NB > 1) GRL_STORE_PLANES(Bs[buf_], trow + RPP, rb1)                                            \
-        if (NB > 2) GRL_STORE_PLANES(Bs[buf_], trow + 2 * RPP, rb2)                                        \
-        if (NB > 2) GRL_STORE_PLANES(Bs[buf_], trow + 3 * RPP, rb3)                                        \
+        GRL_STORE_PLANES_B(Bs[buf_], trow, rb0)                                                            \
+        if (NB > 1) GRL_STORE_PLANES_B(Bs[buf_], trow + RPP, rb1)                                          \
+        if (NB > 2) GRL_STORE_PLANES_B(Bs[buf_], trow + 2 * RPP, rb2)                                      \
+        if (NB > 2) GRL_STORE_PLANES_B(Bs[buf_], trow + 3 * RPP, rb3)                                      \
     }
 
-    f32x4 acc[TM][TN], acl[TM][TN];
+    f32x4 acc[TM][TN], acl[ACC1 ? 1 : TM][ACC1 ? 1 : TN];
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
         for (int b = 0; b < TN; ++b)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[a][b][r] = acl[a][b][r] = 0.f;
+            for (int r = 0; r < 4; ++r) {
+                acc[a][b][r] = 0.f;
+                if constexpr (!ACC1) acl[a][b][r] = 0.f;
+            }
 
     const int nk = K / BK;
     // K-tiles whose tap is outside the image for the WHOLE workgroup are skipped (tile_ok is block-uniform)
@@ -1237,6 +1256,19 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void gemm_rowk(AG ag
         if constexpr (F32) {                                                                                                           \
             mfma_f32_step<TM, TN>(reinterpret_cast<const float *>(&As[cb_][0][0]), reinterpret_cast<const float *>(&Bs[cb_][0][0]),    \
                                   wm * WM + l16, wn * WN + l16, kg, acc);                                                              \
+        } else if constexpr (ACC1) {                                                                                                   \
+            f16x8 af[TM][2];                                                                                                           \
+            _Pragma("unroll") for (int a = 0; a < TM; ++a)                                                                             \
+                _Pragma("unroll") for (int p = 0; p < 2; ++p) af[a][p] = *reinterpret_cast<const f16x8 *>(&As[cb_][p][aro + a * 16 * LDH]); \
+            _Pragma("unroll") for (int b = 0; b < TN; ++b) {                                                                           \
+                f16x8 bf[3];                                                                                                           \
+                _Pragma("unroll") for (int p = 0; p < 3; ++p) bf[p] = *reinterpret_cast<const f16x8 *>(&Bs[cb_][p][bro + b * 16 * LDH]); \
+                _Pragma("unroll") for (int a = 0; a < TM; ++a) {                                                                       \
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[a][1], bf[0], acc[a][b], 0, 0, 0);                           \
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[a][0], bf[1], acc[a][b], 0, 0, 0);                           \
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[a][0], bf[2], acc[a][b], 0, 0, 0);                           \
+                }                                                                                                                      \
+            }                                                                                                                          \
         } else if constexpr (TM < TN) { /* keep the smaller operand's fragments live, stream the other one (fewer registers) */        \
             f16x8 af[TM][2];                                                                                                           \
             _Pragma("unroll") for (int a = 0; a < TM; ++a)                                                                             \
@@ -1311,7 +1343,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void gemm_rowk(AG ag
 #pragma unroll
             for (int b = 0; b < TN; ++b)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[a][b][r] = __builtin_fmaf(acl[a][b][r], 1.0f / kLowScale, acc[a][b][r]);
+                for (int r = 0; r < 4; ++r) {
+                    if constexpr (ACC1) acc[a][b][r] *= 1.0f / kLowScale;      // ... and so does the main term here
+                    else acc[a][b][r] = __builtin_fmaf(acl[a][b][r], 1.0f / kLowScale, acc[a][b][r]);
+                }
     }
     // C/D map of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + reg.  Two passes: all of the epilogue's loads, then
     // the stores (see the epilogue structs).
@@ -1383,6 +1418,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void gemm_rowk(AG ag
 #undef GRL_LOAD_TILE
 #undef GRL_STORE_TILE
 #undef GRL_STORE_PLANES
+#undef GRL_STORE_PLANES_B
 }
 
 // ---------------------------------------------------------------------------- C[I,J] = A^T * B over rows m
