@@ -622,12 +622,14 @@ def test_patch_support_masks_change_nothing_but_the_work(monkeypatch):
     eng.close()
 
 
-def test_the_two_forms_of_conv3s_per_agent_corrections_agree(monkeypatch):
-    """conv3's per-agent corrections are one gather GEMM at the agents' patch pixels (net_gemm.h SlotsToPatch, rows sorted by their set
-    of live taps); GRL_NET_EXPAND3=prod keeps the earlier form (slot products + expansion kernel).  Both add the same terms -- in a
-    different order: one accumulator over the 576-long reduction against a sum of nine 64-long products -- so heads and gradients
-    agree at the float32 level, not bitwise.  Border and corner agents (one to nine live cells), ragged chunks, several tiles per tap
-    class."""
+@pytest.mark.parametrize("knob,modes", [("GRL_NET_EXPAND3", ("gather", "prod")), ("GRL_NET_ACC1", ("on", "off"))])
+def test_two_forms_of_the_same_layer_agree_at_the_float32_level(monkeypatch, knob, modes):
+    """Two A/B switches that change the ORDER of a sum, not its terms, so heads and gradients agree at the float32 level, not bitwise.
+    GRL_NET_EXPAND3: conv3's per-agent corrections are one gather GEMM at the agents' patch pixels (net_gemm.h SlotsToPatch, rows sorted
+    by their set of live taps); `prod` keeps the earlier form (slot products + expansion kernel) -- one accumulator over the 576-long
+    reduction against a sum of nine 64-long products.  GRL_NET_ACC1: three GEMM instances (pol1 + v1, conv2's class corrections, the
+    conv3 gather) keep h.h 2^11 + l'.h + h.l' in ONE accumulator set (a third weight plane h_b 2^11); `off` is the two-set form.
+    Border and corner agents (one to nine live cells), ragged chunks, several tiles per tap class."""
     from goldsrl import _ffi, _ffi_net
     E = 120
     eng = _ffi.Engine(_ffi.ENV_SWARM, E, seed=3)
@@ -645,8 +647,8 @@ def test_the_two_forms_of_conv3s_per_agent_corrections_agree(monkeypatch):
     act, adv, y = _train_inputs(E, seed=16)
     flat = _ffi_net.glorot_uniform_flat(seed=17)
     res = {}
-    for mode in ("gather", "prod"):
-        monkeypatch.setenv("GRL_NET_EXPAND3", mode)      # read when the net is created
+    for mode in modes:
+        monkeypatch.setenv(knob, mode)      # read when the net is created
         net = _ffi_net.ConvNet(eng, max_chunk_samples=500)
         net.set_params(flat)
         out = net.predict_obs(lb, ab, pos)
@@ -654,8 +656,8 @@ def test_the_two_forms_of_conv3s_per_agent_corrections_agree(monkeypatch):
         res[mode] = (out, net.get_grads().copy())
         net.close()
     for k in ("mu", "sigma", "vs"):
-        np.testing.assert_allclose(res["gather"][0][k], res["prod"][0][k], rtol=2e-6, atol=2e-7, err_msg=k)
-    g, h = res["gather"][1], res["prod"][1]
+        np.testing.assert_allclose(res[modes[0]][0][k], res[modes[1]][0][k], rtol=2e-6, atol=2e-7, err_msg=k)
+    g, h = res[modes[0]][1], res[modes[1]][1]
     assert np.isfinite(g).all() and not np.array_equal(g, h)      # two different kernels did run
     gb, hb = NN.unflatten_params(g.astype(np.float64)), NN.unflatten_params(h.astype(np.float64))
     for name in hb:
