@@ -283,7 +283,7 @@ static void launch_rowk(grl_net *net, dim3 grid, hipStream_t st, AG ag, const fl
     // eight-wave 256 x 64 instances spill 16-96 bytes at the 80 registers a third workgroup needs, the four-wave 64 x 64-per-wave tiles
     // 320.  Measured on every instance it fits (round 4, per 81 920-sample chunk): pol1 + v1 190 -> 173 us, conv2's class corrections
     // 113 -> 102, the conv3 patch gather 124 -> 120 (interior 390 -> 379); the other dense forwards / data gradients -2 ... -3 %; the
-    // NBUF = 2 instances +3 ... +7 % (80 KB of LDS), EpiGradSum +29 % (44 bytes of scratch) -- so the three that gain use it.  (It also
+    // NBUF = 2 instances +3 ... +7 % (80 KB of LDS), EpiGradSum +29 % (44 bytes of scratch) -- so the ones that gain use it.  (It also
     // changes the rounding of a sum, so the two forms of a layer that a test compares bit for bit must agree on it.)
     constexpr bool kAcc1 = ACC1 && ((WGM * WGN == 8 && BM == 128 && BN == 128) || (WGM * WGN == 4 && BM * BN <= 128 * 64));
     if (net->gemm_f32)
