@@ -254,6 +254,47 @@ def test_a_range_violation_moves_the_net_to_fp32_gemms_and_the_call_proceeds():
         n_.close()
 
 
+def test_a_weight_beyond_the_one_accumulator_forms_range_takes_the_same_way_out():
+    """Three forward GEMM instances keep h_a h_b 2^11 + l'_a h_b + h_a l'_b in ONE accumulator set (net_gemm.h, ACC1): the weight
+    operand's third plane h_b * 2^11 is exact in fp16 while |w| < 32.  A larger weight makes that plane inf, the tile's outputs inf /
+    NaN, and the range guard treats them like any other operand outside the fp16 range: the pass is run again on the fp32 form.
+    pol1_w[0, 0] = 40 (pol1 + v1 is one of the three): predict and the gradient against the float64 oracle, and the counters."""
+    E = 2
+    eng, net, p, states, obs = _setup(E)
+    q = NN.unflatten_params(net.get_params().astype(np.float64))
+    q["pol1_w"][0, 0] = 40.0
+    q["pol1_w"][5, 7] = -33.0
+    net.set_params(NN.flatten_params(q).astype(np.float32))
+    q = NN.unflatten_params(net.get_params().astype(np.float64))
+    out = net.predict()
+    assert net.range_info() == {"gemm_f32": True, "fallbacks": 1, "update_skipped": False}
+    mu, sigma, vs, c = NN.conv_forward(q, states, 1000.0, keep=True)
+    assert np.abs(c["a2"]).max() < 65504      # the activations themselves are inside the range: it is the weight plane that is not
+    np.testing.assert_allclose(out["mu"], mu, atol=1e-5)
+    np.testing.assert_allclose(out["sigma"], sigma, atol=1e-5)
+    np.testing.assert_allclose(out["vs"], vs, rtol=2e-5, atol=1e-4)
+    act, adv, y = _train_inputs(E)
+    stats = net.train_obs(*obs, act, adv, y, lr=0.0, apply_update=False)
+    assert np.isfinite(stats["global_norm"]) and net.range_info()["fallbacks"] == 1
+    got = NN.unflatten_params(net.get_grads().astype(np.float64))
+    loss, pl, cl, gref, _ = NN.conv_loss_and_grads(q, states, act.astype(np.float64), adv.astype(np.float64), y.astype(np.float64), 0.02, 1000.0)
+    for name, _ in NN.CONV_PARAM_SHAPES:
+        assert np.abs(got[name] - gref[name]).max() <= 2e-4 * (np.abs(gref[name]).max() + 1e-12), name
+    # weights of 31.9 are inside: no fallback, same comparison
+    eng2, net2, _, _, _ = _setup(E)
+    q["pol1_w"][0, 0] = 31.9
+    q["pol1_w"][5, 7] = -31.9
+    net2.set_params(NN.flatten_params(q).astype(np.float32))
+    q = NN.unflatten_params(net2.get_params().astype(np.float64))
+    out2 = net2.predict()
+    assert net2.range_info() == {"gemm_f32": False, "fallbacks": 0, "update_skipped": False}
+    mu, sigma, vs, _ = NN.conv_forward(q, states, 1000.0, keep=True)
+    np.testing.assert_allclose(out2["mu"], mu, atol=1e-5)
+    np.testing.assert_allclose(out2["sigma"], sigma, atol=1e-5)
+    np.testing.assert_allclose(out2["vs"], vs, rtol=2e-5, atol=1e-4)
+    net.close(); net2.close()
+
+
 def test_a_rollout_that_left_the_range_gives_its_update_up_and_the_next_one_is_valid():
     """A rollout whose forward passes overflowed drew its actions from invalid heads: the gradient step over it is given up
     (GRL_OK, parameters and Adam moments untouched, update_skipped in grl_net_range_info), the net moves to the fp32 form, and
