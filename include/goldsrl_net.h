@@ -13,7 +13,7 @@
  * Arithmetic: float32 in, float32 out, float32 accumulation, as the reference's TF graph.  conv2, conv3 and the dense layers run
  * on the fp16 matrix pipe with every fp32 operand split into two fp16 terms (22-23 significand bits; csrc/net_gemm.h), which
  * measures closer to a float64 evaluation than a plain float32 one.  Range contract of that form: activations and weights
- * below 65 504 in magnitude (since round 4 the weights of conv3, pol1 and v1 below 32: the GEMM instances that read them keep one
+ * below 65 504 in magnitude (since round 4 the weights of conv2, conv3, pol1 and v1 below 32: the GEMM instances that read them keep one
  * accumulator set, whose third weight plane holds h_w * 2^11; a larger weight takes the same way out as any other violation).  Nothing is clamped: every GEMM checks its output tile, and the first call that synchronises
  * after a violation (predict, train_*, apply_grads) does not return results computed from inf operands.  By default it switches the
  * net to the fp32 form of the same GEMM kernels (v_mfma_f32_16x16x4_f32, no range beyond float32's, an update of the headline configuration takes 0.50 s instead of 0.33: 1.5x, round 4; the net
