@@ -38,6 +38,9 @@ class _GradientExchange(object):
 class ConvPolicyRollout(_GradientExchange):
     def __init__(self, eng, T, train=True, lr=1e-4, reward_layout=0, seed=3, chunk=81920, **net_kw):
         self.eng, self.T, self.train, self.lr, self.reward_layout = eng, T, train, lr, reward_layout
+        import os
+        if os.environ.get("GRL_NET_CHUNK"):      # tuning knob: samples per chunk (a multiple of 10, <= 131 072)
+            chunk = int(os.environ["GRL_NET_CHUNK"])
         chunk = min(chunk, eng.E * 10)
         self.net = _ffi_net.ConvNet(eng, max_chunk_samples=chunk, **net_kw)
         self.net.set_params(_ffi_net.glorot_uniform_flat(seed))
