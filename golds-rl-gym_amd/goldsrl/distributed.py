@@ -48,8 +48,12 @@ def _recv_exact(sock, n):
     return bytes(buf)
 
 
-def _recv(sock):
+def _recv(sock, limit=None):
+    """One frame.  `limit` bounds the length header BEFORE anything is allocated: during the handshake the other end may be anybody
+    (an HTTP server answering 'HTTP/1.1 400', a scanner sending 'GET / HT' read as a length of ~6e18)."""
     (n,) = _HDR.unpack(_recv_exact(sock, _HDR.size))
+    if limit is not None and n > limit:
+        raise ConnectionError("rendezvous: a frame of %d bytes where at most %d can be this job's" % (n, limit))
     return _recv_exact(sock, n)
 
 
@@ -132,12 +136,12 @@ class Ranks(object):
                     continue
                 c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                 c.settimeout(5.0)
+                want = _HELLO + nonce.encode()
                 try:
-                    hello = _recv(c)
-                except (OSError, ConnectionError):
+                    hello = _recv(c, len(want) + 4)
+                except (OSError, ConnectionError):      # not framed like a rank's hello (or nothing at all): not a peer
                     c.close()
                     continue
-                want = _HELLO + nonce.encode()
                 if len(hello) != len(want) + 4 or hello[:len(want)] != want:
                     c.close()                        # not a rank of this job (port scanner, a peer of another job): ignore it
                     continue
@@ -166,7 +170,7 @@ class Ranks(object):
                     s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                     s.settimeout(5.0)
                     _send(s, _HELLO + nonce.encode() + struct.pack("<i", self.rank))
-                    if _recv(s) != _ACK + nonce.encode():
+                    if _recv(s, len(_ACK) + len(nonce.encode())) != _ACK + nonce.encode():
                         raise ConnectionError("the listener on port %d is not this job's rank 0" % port)
                     break
                 except (OSError, ValueError, ConnectionError) as e:   # file not there yet, stale port, rank 0 not listening yet, foreign listener

@@ -7,6 +7,8 @@ import subprocess
 import sys
 import time
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "golds-rl-gym_amd"))
 
@@ -226,9 +228,12 @@ def test_host_exchange_update_is_taken_or_left_by_every_rank_together(tmp_path):
     assert sorted(p.name for p in tmp_path.iterdir() if p.name.startswith("ok")) == ["ok0", "ok1"]
 
 
-def test_a_stale_rendezvous_file_pointing_at_a_foreign_listener_is_rejected(tmp_path):
+@pytest.mark.parametrize("answer", [b"\x05\x00\x00\x00\x00\x00\x00\x00hello", b"HTTP/1.1 400 Bad Request\r\n\r\n", b""],
+                         ids=["framed", "raw-http", "silent"])
+def test_a_stale_rendezvous_file_pointing_at_a_foreign_listener_is_rejected(tmp_path, answer):
     """A crashed job can leave its port file behind and the port may since belong to somebody else (round-3 advisor finding): rank 1
-    reads the stale file first, reaches a listener that does not answer with this job's nonce, drops it and keeps polling; rank 0
+    reads the stale file first, reaches a listener that does not answer with this job's nonce -- a well-formed frame, raw bytes whose
+    first eight read as a length of ~5e18 (round-4 advisor finding: bounded before anything is allocated), or nothing -- drops it and keeps polling; rank 0
     removes the stale file, publishes its own port + nonce, and the two meet.  The file lives in a 0700 directory of this user."""
     import socket
     import stat
@@ -250,7 +255,7 @@ def test_a_stale_rendezvous_file_pointing_at_a_foreign_listener_is_rejected(tmp_
                 continue
             hits.append(1)
             try:
-                c.settimeout(1.0); c.recv(64); c.sendall(b"\x05\x00\x00\x00\x00\x00\x00\x00hello")
+                c.settimeout(1.0); c.recv(64); c.sendall(answer)
             except OSError:
                 pass
             c.close()
@@ -279,3 +284,49 @@ def test_a_stale_rendezvous_file_pointing_at_a_foreign_listener_is_rejected(tmp_
     assert out == {0: 3.0, 1: 3.0}
     assert hits, "rank 1 never tried the stale port (the test did not exercise the rejection)"
     assert not os.path.exists(path)      # rank 0 removes its file on close
+
+
+def test_rank_0_drops_a_client_that_does_not_speak_the_handshake():
+    """The other direction of the same finding: something that is not a rank connects to rank 0's port and sends raw bytes (their
+    first eight read as a frame length of ~5e18).  Rank 0 must close that connection and go on accepting -- not die allocating."""
+    import socket
+    import threading
+    from goldsrl import distributed as D
+    key = "scan-test-%d" % os.getpid()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); mport = s.getsockname()[1]; s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(mport), GRL_RDZV_KEY=key, WORLD_SIZE="2")
+    env.pop("GRL_STORE_PORT", None)
+    path = D._rendezvous_file(env)
+    if os.path.exists(path):
+        os.unlink(path)
+    out, scanned = {}, threading.Event()
+
+    def scanner():
+        deadline = time.time() + 30
+        while time.time() < deadline:
+            try:
+                with open(path) as f:
+                    port = int(f.read().split()[0])
+                break
+            except (OSError, ValueError, IndexError):
+                time.sleep(0.02)
+        for raw in (b"GET / HTTP/1.1\r\nHost: x\r\n\r\n", b"\xff" * 8, b"abc"):
+            c = socket.create_connection(("127.0.0.1", port), timeout=5)
+            c.sendall(raw)
+            time.sleep(0.2)
+            c.close()
+        scanned.set()
+
+    def rank(r):
+        rk = D.Ranks(dict(env, RANK=str(r), LOCAL_RANK=str(r)))
+        if r == 1:
+            assert scanned.wait(60)
+        rk.init(timeout_s=60)
+        out[r] = rk.sum(1.0 + r)
+        rk.close()
+    ts = [threading.Thread(target=f, args=a) for f, a in ((scanner, ()), (rank, (0,)), (rank, (1,)))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(120)
+    assert out == {0: 3.0, 1: 3.0}
