@@ -54,6 +54,8 @@ MFMA_F16_PEAK_TFLOPS = 2516.6        # MI355X_MICROARCH.md: dense fp16 / bf16 ma
 F16_PRODUCTS_PER_FP32 = 3
 MFMA_X3_PEAK_TFLOPS = MFMA_F16_PEAK_TFLOPS / F16_PRODUCTS_PER_FP32
 GEMM_TRAFFIC_FILE = "r04_gemm_traffic.json"   # PMC pass of the GEMM kernels (tools/run_prof.sh); refreshed per round
+GEMM_TRAFFIC_FILE_INTERIOR = "r05_gemm_traffic_interior.json"   # the same pass on the interior_policy state distribution
+SHARD_ENVS = 4096                             # 32 768 / 8: one GPU's share of BASELINE's target shape (strong scaling)
 
 
 def parse():
@@ -77,6 +79,7 @@ def parse():
                     help="profiling aid: run the main measurement on the interior_policy state distribution (agents re-injected into the "
                          "interior of the box before every update, outside the clock)")
     ap.add_argument("--no-legs", action="store_true", help="skip the dense_form / interior_policy legs (two more 32 768-env jobs)")
+    ap.add_argument("--no-shard", action="store_true", help="skip the strong-scaling shard leg (the full update at 32 768 / 8 envs)")
     ap.add_argument("--no-flat-configs", action="store_true", help="skip the Solow-4096 / TradeAR1-16 side blocks (configs 2 and 5)")
     ap.add_argument("--exchange", default="rccl", choices=["rccl", "host"],
                     help="gradient exchange for N>1: RCCL all-reduce inside the library (falls back together if any rank cannot "
@@ -125,7 +128,7 @@ def _cpu_cores():
     return min(ncores, 32)
 
 
-def cpu_baseline(sample_envs, T, full_update_envs=48):
+def cpu_baseline(sample_envs, T, full_update_envs=48, mask=None):
     """CPU baseline from the oracle ("port"), bounded sample of the SAME workload: a full PAAC update
     (dense 84x84x3 images as the reference builds them, conv policy forward per step, C env step + observation,
     n-step returns, loss + backward over the T*E*10 samples) on `full_update_envs` envs; numpy/BLAS threads +
@@ -133,6 +136,20 @@ def cpu_baseline(sample_envs, T, full_update_envs=48):
     from oracle import nets as NN
     from oracle import oracle as O
     from oracle import oracle_c as OC
+    # The baseline uses the cores the JOB was granted, not the NUMA node the rank's enqueue thread was pinned to for the GPU part
+    # (advisor r4: pinned first, `allcores` silently became the node's cores): the mask from before the pin is put back for the
+    # duration (threads the OpenMP runtime creates in here inherit it), the pin restored afterwards.
+    pinned = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
+    if mask and pinned is not None and set(mask) != set(pinned):
+        os.sched_setaffinity(0, mask)
+    try:
+        return _cpu_baseline(sample_envs, T, full_update_envs, NN, O, OC)
+    finally:
+        if mask and pinned is not None and set(mask) != set(pinned):
+            os.sched_setaffinity(0, pinned)
+
+
+def _cpu_baseline(sample_envs, T, full_update_envs, NN, O, OC):
     ncores = _cpu_cores()
     try:
         from threadpoolctl import threadpool_limits
@@ -284,7 +301,33 @@ def inject_interior_agents(eng, rng):
     return float(((pos >= 8) & (pos <= 75)).all(axis=2).mean())
 
 
-def workload_leg(args, ranks, E, T, env=None, interior=False, steps=3):
+def family_table(gemm_tags, gfam=None):
+    """Per GEMM family of one single-stream profiling pass: launches, ms, achieved TFLOP/s of executed fp32 work and its fraction of the
+    three-product matrix-pipe roof; with gfam (HBM-side bytes per launch of a committed PMC pass of the SAME workload and chunk size)
+    also the HBM fraction of the live launch duration and which roof is nearer."""
+    out = {k: {"launches": v[0], "ms": v[1], "achieved": v[2] / (v[1] * 1e-3) / 1e12 if v[1] > 0 else 0.0,
+               "frac": (v[2] / (v[1] * 1e-3) / 1e12 / MFMA_X3_PEAK_TFLOPS) if v[1] > 0 else 0.0} for k, v in gemm_tags.items()}
+    for k, v in out.items():
+        pf = (gfam or {}).get(k)
+        if pf and v["launches"] > 0 and v["ms"] > 0:
+            tbps = pf["hbm_bytes_per_launch"] / (v["ms"] * 1e-3 / v["launches"]) / 1e12
+            v["hbm_bytes_per_launch"] = pf["hbm_bytes_per_launch"]
+            v["hbm_TBps"] = tbps
+            v["hbm_frac"] = tbps / (HBM_PEAK_GBS / 1e3)
+            v["bound"] = "hbm" if v["hbm_frac"] > v["frac"] else "mfma"
+    return out
+
+
+def load_traffic(name):
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return None, {}
+    with open(path) as f:
+        gj = json.load(f)
+    return gj.get("hbm_bytes_per_launch"), gj.get("by_family", {})
+
+
+def workload_leg(args, ranks, E, T, env=None, interior=False, steps=3, traffic_file=None):
     """The same full PAAC update as `value`, on one more form of the evaluation (env: GRL_* switches read when the net is created) or
     one more state distribution (interior: agents re-injected into the interior of the box before every update, outside the timed
     region): ms per update, env-steps/s, and -- from a single-stream pass with HIP events around every GEMM -- the executed share
@@ -324,15 +367,28 @@ def workload_leg(args, ranks, E, T, env=None, interior=False, steps=3):
     roll.net.profile_enable(False)
     dt = sum(per) / len(per)
     contract = 18.10e6 * 10 * E * ((T + 1) + 3 * T)
-    chunk_samples = min(E * 10, 81920)
+    chunk_samples = int(roll.net.cfg.max_chunk_samples)
     patch = {}
     for fam in ("dense1_patch_fwd", "dense1_patch_dgrad", "dense1_patch_wgrad"):
         if fam in tags and tags[fam][0] > 0:
             patch[fam] = tags[fam][2] / (tags[fam][0] * 2.0 * chunk_samples * 1600 * 512)
+    chunks_per_step = -(-E * 10 // chunk_samples)
+    nl = 4 if not os.environ.get("GRL_NET_LANES") else int(os.environ["GRL_NET_LANES"])
     out = {"ms_per_update": dt * 1e3, "ms_per_update_spread": spread(per), "value": E * T / dt, "unit": "env-steps/s", "steps": steps,
            "executed_share": flops / contract, "executed_tflop_per_update": flops / 1e12,
            "patch_support_share": patch, "gemm_ms_single_stream": ms, "gemm_tflops": flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
-           "gemm_frac": (flops / (ms * 1e-3) / 1e12 / MFMA_X3_PEAK_TFLOPS) if ms > 0 else 0.0}
+           "gemm_frac": (flops / (ms * 1e-3) / 1e12 / MFMA_X3_PEAK_TFLOPS) if ms > 0 else 0.0,
+           "chunk_samples": chunk_samples, "chunks_per_step": chunks_per_step,
+           # stream lanes with work: a rollout gives every chunk of a step its own T-step pipeline, the gradient step deals its
+           # T x chunks_per_step chunks round-robin
+           "lanes_busy": {"rollout": min(nl, chunks_per_step), "gradient_step": min(nl, T * chunks_per_step), "lanes": nl}}
+    gtraffic, gfam = load_traffic(traffic_file) if traffic_file else (None, {})
+    out["roofline"] = {"bound": "mfma", "achieved": out["gemm_tflops"], "peak": MFMA_X3_PEAK_TFLOPS, "unit": "TFLOP/s",
+                       "frac": out["gemm_frac"], "traffic": gtraffic,
+                       "traffic_source": ("from_profile: profiles/%s (PMC passes of this workload at the same chunk size)" % traffic_file)
+                       if gfam else None,
+                       "by_family": family_table(tags, gfam),
+                       "measured": "HIP event pair around every GEMM launch of one extra single-stream update of this leg"}
     if interior:
         out["agents_inside_bins_8_75"] = sum(shares) / len(shares)
     roll.net.close(); eng.close()
@@ -439,6 +495,7 @@ def main():
     # One process per GPU: keep this rank's host thread (and every thread the HIP runtime / RCCL start later) on the cores of its
     # GPU's NUMA node.  Found in sysfs, applied BEFORE anything touches the GPU (goldsrl/affinity.py); reported in the line.
     from goldsrl import affinity
+    mask0 = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None      # what the job may use (cpu_baseline runs on it)
     local = int(os.environ.get("GRL_BENCH_FORCE_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     pin = affinity.pin_to_gpu(local)
 
@@ -500,12 +557,28 @@ def main():
         extras["dense_form"] = workload_leg(args, ranks, E, T, env={"GRL_PATCH_SKIP": "off", "GRL_TRUNK_SKIP": "off"})
         extras["dense_form"]["what"] = ("the same update with GRL_PATCH_SKIP=off GRL_TRUNK_SKIP=off: plain 5x5 dense1 patches, all 9 conv3 taps of "
                                         "every slot, the env-level trunk over every pixel (no row lists, no background terms, no union mask)")
-        extras["interior_policy"] = workload_leg(args, ranks, E, T, interior=True)
+        extras["interior_policy"] = workload_leg(args, ranks, E, T, interior=True, traffic_file=GEMM_TRAFFIC_FILE_INTERIOR)
         extras["interior_policy"]["what"] = ("the same update (default zero-skipping forms) on a state distribution with the agents INSIDE the "
                                              "observation box -- positions injected before every update, outside the timed region: x = "
                                              "mean_x + U(-1.2, 0), y = U(1.5, 4.3) -- where an agent's conv3 footprint is ~75 % of its 5x5 "
                                              "patch instead of ~25 % at the rim; `value` above stays on SURVEY 8(d)'s prescribed workload "
                                              "(random-init policy from the env's own reset states)")
+    if world == 1 and not args.no_extras and not args.no_shard and args.policy == "conv" and not args.no_train and not args.single_stream:
+        # the per-GPU share of the shape BASELINE's target is quoted on (32 768 Swarm envs over 8 GPUs, >= 6x of the 1-GPU rate): the
+        # same full update at 4 096 envs.  On one GPU this prices everything of that point except the 8.84 MB all-reduce.
+        sh = workload_leg(args, ranks, SHARD_ENVS, T, steps=7)
+        sh["ms_per_update"] = sh["ms_per_update_spread"]["median"]
+        sh["value"] = SHARD_ENVS * T / (sh["ms_per_update"] * 1e-3)
+        one = elapsed / args.steps * 1e3 * (32768.0 / E)
+        sh["what"] = ("the same full PAAC update at %d envs = 32 768 / 8, median of %d: one rank's work at the strong-scaling point of "
+                      "BASELINE's target" % (SHARD_ENVS, sh["steps"]))
+        sh["projected_8gpu"] = {"measured": False,
+                                "speedup_1_to_8": one / sh["ms_per_update"],
+                                "env_steps_per_s": 32768 * T / (sh["ms_per_update"] * 1e-3),
+                                "note": "PROJECTED, not measured: ms_per_step of this run (scaled to 32 768 envs) / this leg's median; "
+                                        "it leaves out the all-reduce of the 2.2 M-float gradient (8.84 MB per rank and update over "
+                                        "xGMI) and the ranks' mutual wait -- RCCL with world size > 1 has not run on any box yet"}
+        extras["shard_%d" % SHARD_ENVS] = sh
     if world == 1 and not args.no_flat_configs and not args.no_extras and args.policy == "conv":
         device = int(os.environ.get("GRL_BENCH_FORCE_DEVICE", ranks.local_rank))
         extras["solow_4096"] = flat_config_block("solow", 4096, T, device)
@@ -571,12 +644,7 @@ def main():
         if gemm is not None:
             launches, ms, flops = gemm
             ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-            gtraffic, gfam = None, {}      # HBM bytes per GEMM launch from the committed PMC passes (same 81 920-sample chunks)
-            gpath = os.path.join(ROOT, "profiles", GEMM_TRAFFIC_FILE)
-            if os.path.exists(gpath):
-                with open(gpath) as f:
-                    gj = json.load(f)
-                gtraffic, gfam = gj.get("hbm_bytes_per_launch"), gj.get("by_family", {})
+            gtraffic, gfam = load_traffic(GEMM_TRAFFIC_FILE)      # HBM bytes per GEMM launch from the committed PMC passes (same 81 920-sample chunks)
             out["roofline"] = {"bound": "mfma",
                                "kernel": "gemm_rowk / gemm_tn (fp32 implicit GEMMs: operands split into 2 fp16 terms, "
                                          "3 v_mfma_f32_16x16x32_f16 per 16x16 tile and K=32 step, fp32 accumulation)",
@@ -605,20 +673,13 @@ def main():
                                            "region on a single stream (%.1f ms); the timed region itself deals chunks round-robin "
                                            "to four streams (GRL_NET_F_SINGLE_STREAM off)" % (gemm_step_s * 1e3 if gemm_step_s else 0.0),
                                "flops_per_launch_avg": flops / max(launches, 1),
-                               "by_family": {k: {"launches": v[0], "ms": v[1], "achieved": v[2] / (v[1] * 1e-3) / 1e12 if v[1] > 0 else 0.0,
-                                                 "frac": (v[2] / (v[1] * 1e-3) / 1e12 / MFMA_X3_PEAK_TFLOPS) if v[1] > 0 else 0.0}
-                                             for k, v in gemm_tags.items()}}
-            # which roof a family is nearer: the live duration of its launches against the matrix pipe (frac) and against HBM (hbm_frac:
-            # HBM-side bytes per launch of the committed PMC passes of the same chunk size / the live average launch duration / 8 TB/s);
-            # the N <= 64 families (conv gathers, slots, class corrections) are byte bound, the square dense ones sit under both roofs
-            for k, v in out["roofline"]["by_family"].items():
-                pf = gfam.get(k)
-                if pf and v["launches"] > 0 and v["ms"] > 0:
-                    tbps = pf["hbm_bytes_per_launch"] / (v["ms"] * 1e-3 / v["launches"]) / 1e12
-                    v["hbm_bytes_per_launch"] = pf["hbm_bytes_per_launch"]
-                    v["hbm_TBps"] = tbps
-                    v["hbm_frac"] = tbps / (HBM_PEAK_GBS / 1e3)
-                    v["bound"] = "hbm" if v["hbm_frac"] > v["frac"] else "mfma"
+                               # which roof a family is nearer: the live duration of its launches against the matrix pipe (frac) and
+                               # against HBM (hbm_frac: HBM-side bytes per launch of the committed PMC passes of the same chunk size /
+                               # the live average launch duration / 8 TB/s); the N <= 64 families (conv gathers, slots, class
+                               # corrections) are byte bound, the square dense ones sit under both roofs
+                               "by_family": family_table(gemm_tags, gfam)}
+            for v in out["roofline"]["by_family"].values():
+                if "hbm_frac" in v:
                     v["traffic_source"] = "from_profile: profiles/%s" % GEMM_TRAFFIC_FILE
             # SURVEY 8(d)'s algorithmic figure: the reference evaluates the net once per agent-sample, 18.10 MFLOP forward, backward = 2x
             # forward; an update = (T + 1) rollout forwards + T training forwards and backwards over E * 10 agent-samples
@@ -644,7 +705,8 @@ def main():
         if last_stats:
             out["last_update_stats"] = last_stats
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample_envs, T)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample_envs, T, mask=mask0)
+            out["cpu_baseline"]["affinity"] = "the job's own mask (%s cpus), not the GPU rank's NUMA pin" % (len(mask0) if mask0 else "?")
         print(json.dumps(out))
         sys.stdout.flush()
     ranks.barrier()

@@ -302,6 +302,7 @@ struct DenseRows {   // plain row-major [rows][ld], reduction length k
 // in the bias), the data gradient does not compute their column tiles (only their sum over the envs is needed: closed form), the
 // weight gradient writes no slab tile for their rows (rank-1 closed form).
 struct DenseRowsKU : DenseRows {
+    static constexpr int kMaxK = 64 * 64;      // wg_ctx carries u[0..1]: 64 pixel bits (checked where the instance is launched)
     const unsigned *u;
     __device__ __forceinline__ unsigned long long wg_ctx(int) const { return (unsigned long long)u[0] | ((unsigned long long)u[1] << 32); }
     __device__ __forceinline__ bool tile_ok_c(unsigned long long c, int k0) const { return (c >> (k0 >> 6)) & 1ull; }
@@ -594,6 +595,7 @@ struct PatchRows {
         ty = tx = 0;
     }
     __device__ __forceinline__ bool ok(int iy0, int, int, int) const { return iy0 >= 0; }
+    static constexpr int kMaxK0 = 32 * 64;    // mode 0: a 32-bit support word, one bit per 64-wide pixel (checked where launched)
     struct Ctx { unsigned tm; int b0; };      // the tile's support union; dense1 row of the group's patch pixel (0,0)
     __device__ __forceinline__ Ctx wg_ctx(int m0) const {      // gemm_rowk, BM = 128
         Ctx c{0xFFFFFFFFu, 0};
@@ -604,7 +606,9 @@ struct PatchRows {
         }
         return c;
     }
-    __device__ __forceinline__ bool tile_ok_c(const Ctx &c, int k0) const { return (c.tm >> (k0 >> 6)) & 1u; }      // mode 0: K-tile k0 lies in one patch pixel
+    __device__ __forceinline__ bool tile_ok_c(const Ctx &c, int k0) const {      // mode 0: K-tile k0 lies in one patch pixel
+        return mode != 0 || ((c.tm >> ((k0 >> 6) & 31)) & 1u);                      // (other modes: K is not the patch, no shift by k0)
+    }
     __device__ __forceinline__ int bk_c(const Ctx &c, int k0) const {
         if (mode != 0) return k0;
         const int py = k0 / 320;
@@ -616,6 +620,25 @@ struct PatchRows {
         const int g = tilegroup[m0 >> 8], oy = g / 3, ox = g - oy * 3;
         const int j = n0 >> 6, py = j / 5, px = j - py * 5;
         return ((oy + py) * 7 + ox + px) * 64 + (n0 & 63);
+    }
+};
+
+// PatchRows for gemm_tn with 128-wide I tiles made of TWO LIVE patch pixels (round 5).  The weight gradient's I axis is the patch
+// (25 pixels x 64 channels) and a slice's support union zmask[z] says which pixels any of its rows can have non-zero; the 64 x 128
+// tiles of round 3 skipped the dead pixels one by one.  Here grid x = t takes the (2t)-th and (2t+1)-th SET bit of zmask[z]: a
+// 128 x 128 tile whose two 64-column halves are two arbitrary live pixels (the last tile of an odd count has one) -- the tile shape
+// of the dense layers' weight gradients (half the B re-reads and LDS fragment reads per MFMA of the 64-wide form) on exactly the live
+// pixels, in both support regimes.  Every output element is the same sum over the same K-tiles of 32 rows: bit-identical slabs.
+struct PatchRowsPair : PatchRows {
+    static constexpr bool kPairI = true;
+    // the tile's two pixels (second: -1 if the slice has an odd number of live pixels and this is its last tile; first: -1 = no tile)
+    __device__ __forceinline__ int2 pair(int z, int t) const {
+        unsigned zm = zmask ? zmask[z] : 0x1FFFFFFu;
+        for (int s = 0; s < 2 * t; ++s) zm &= zm - 1u;
+        if (!zm) return make_int2(-1, -1);
+        const int p0 = __ffs(zm) - 1;
+        zm &= zm - 1u;
+        return make_int2(p0, zm ? __ffs(zm) - 1 : -1);
     }
 };
 
@@ -1098,6 +1121,8 @@ template <class T, class = void> struct ag_has_n_ok : std::false_type {};
 template <class T> struct ag_has_n_ok<T, std::void_t<decltype(std::declval<const T &>().n_ok(0, 0))>> : std::true_type {};
 template <class T, class = void> struct ag_has_i_ok : std::false_type {};
 template <class T> struct ag_has_i_ok<T, std::void_t<decltype(std::declval<const T &>().i_ok(0, 0))>> : std::true_type {};
+template <class T, class = void> struct ag_pair_i : std::false_type {};
+template <class T> struct ag_pair_i<T, std::void_t<decltype(T::kPairI)>> : std::bool_constant<T::kPairI> {};
 
 // ---------------------------------------------------------------------------- C = A(rowk) * Bt^T
 // Four or eight waves per workgroup (WGM x WGN).  The eight-wave forms keep a tile's bytes per FLOP and halve the wave tile
@@ -1466,16 +1491,22 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void gemm_tn(AG ag, 
             bx = t - by * nx;
         }
     }
+    constexpr bool PAIR = ag_pair_i<AG>::value;      // the I tile is two independent 64-column runs (PatchRowsPair)
     const int i0 = bx * BM, j0 = by * BN;
     const int I = ag.K();
     int mbeg, mend;
     ag.mrange(bz, mc, mbeg, mend);
-    if constexpr (ag_has_i_ok<AG>::value) {      // output rows that are zero for the whole row range: no slab tile; the reduction
+    int2 pp = make_int2(0, 0);
+    if constexpr (PAIR) {
+        static_assert(!PAIR || BM == 128, "two 64-column halves");
+        pp = ag.pair(bz, bx);
+        if (pp.x < 0) return;                    // fewer live pixels than this tile's first: no slab tile
+    } else if constexpr (ag_has_i_ok<AG>::value) {      // output rows that are zero for the whole row range: no slab tile; the reduction
         if (!ag.i_ok(bz, i0)) return;            // that follows knows the same masks (patch_dw_reduce_kernel)
     }
 
     int toff, ty, tx;
-    ag.tap(i0, toff, ty, tx);   // the BM-wide column run lies inside one tap row (checked on the host)
+    ag.tap(PAIR ? 0 : i0, toff, ty, tx);   // the BM-wide column run lies inside one tap row (checked on the host)
 
     // this thread's part of a tile: rows NA*(tid/A4) .. +NA-1 (A), NB*(tid/B4) .. +NB-1 (B), columns 4*ca .. 4*ca+3 / 4*cb ..
     // LDS has 32 banks of 4 bytes: a store instruction is served 128 bytes (32 x 4-byte or 16 x 8-byte lanes) per pass.  With the
@@ -1492,6 +1523,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void gemm_tn(AG ag, 
     if (NB == 2) gb ^= ((cb >> 1) & 1) << 1;
     if (NB == 1) gb ^= ((cb >> 1) & 1) << 2;      // one row per thread, stored as (m, m+1) pairs after a lane exchange: see GRL_STORE_TILE
     const int ma = NA * ga, mb = NB * gb;
+    // column offset of this thread's four A columns inside the row, and whether its half of a pixel pair exists
+    const int acol = PAIR ? ((ca < 16 ? pp.x : max(pp.y, 0)) * 64 + (ca & 15) * 4) : toff + ca * 4;
+    const bool ahalf_ok = !PAIR || ca < 16 || pp.y >= 0;
     float4 ra[NA], rb[NB];
     unsigned vma = 0, vmb = 0;
     // physical rows of the tile about to be loaded (-1: past the range / padding).  They are fetched one tile ahead of
@@ -1518,8 +1552,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void gemm_tn(AG ag, 
             const bool inr = (iva >> i) & 1u;                                                                      \
             long off; int iy0, ix0;                                                                                \
             ag.rowh(ia[i], off, iy0, ix0);                                                                         \
-            const bool v = inr && ag.ok(iy0, ix0, ty, tx);                                                         \
-            ra[i] = *reinterpret_cast<const float4 *>(ag.base + (v ? off + toff : 0L) + ca * 4);                   \
+            const bool v = inr && ahalf_ok && ag.ok(iy0, ix0, ty, tx);                                             \
+            ra[i] = *reinterpret_cast<const float4 *>(ag.base + (v ? off + acol : (long)(ca * 4)));                \
             vma = v ? (vma | (1u << i)) : (vma & ~(1u << i));                                                      \
         }                                                                                                          \
         _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                           \
@@ -1671,8 +1705,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void gemm_tn(AG ag, 
             for (int r = 0; r < 4; ++r) {
                 const int pa = wm * WM + a * 16 + 4 * kg + r;      // LDS rows -> tile columns
                 const int pb = wn * WN + b * 16 + l16;
-                const int row = i0 + 4 * (pa % A4) + pa / A4;
+                int row = i0 + 4 * (pa % A4) + pa / A4;
                 const int col = j0 + 4 * (pb % B4) + pb / B4;
+                if constexpr (PAIR) {      // tile column c: pixel of its half, channel c & 63
+                    const int c = row - i0, px = c < 64 ? pp.x : pp.y;
+                    row = px < 0 ? I : px * 64 + (c & 63);
+                }
                 if (row < I && col < J) out[(long)row * J + col] = acc[a][b][r];
             }
 #undef GRL_LOAD_TILE

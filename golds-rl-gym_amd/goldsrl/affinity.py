@@ -3,8 +3,10 @@
 The reference splits its envs over worker PROCESSES and leaves their placement to the OS (fed_gym/agents/paac/runners.py:18-54).
 Here a rank's host side is one thread that enqueues ~10^4 kernel launches per PAAC update on four HIP streams plus RCCL's proxy
 threads; on an 8-GPU host with two sockets a rank that runs on the far socket pays the inter-socket hop on every doorbell and
-every completion signal, and eight unpinned ranks migrate over each other.  `pin_to_gpu(ordinal)` restricts the calling process to
-the cores of the GPU's NUMA node -- found in sysfs, WITHOUT any HIP call, so that it can run before the runtime starts its threads:
+every completion signal, and eight unpinned ranks migrate over each other.  `pin_to_gpu(ordinal)` restricts the CALLING THREAD (and
+every thread created after the call, which inherits the mask: the HIP runtime's and RCCL's, when it runs before they start) to
+the cores of the GPU's NUMA node -- found in sysfs, WITHOUT any HIP call.  Threads that exist already keep their mask:
+`os.sched_setaffinity(0, ...)` is per thread on Linux, so e.g. the BLAS / OpenMP pools numpy created at import stay where they were.
 
   /sys/class/kfd/kfd/topology/nodes/<k>/properties   `simd_count` > 0 marks a GPU node (node order = HIP ordinal order),
                                                      `domain`, `location_id` = its PCI address (bus << 8 | device << 3 | function)

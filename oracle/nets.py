@@ -229,14 +229,22 @@ def relu_ambiguous(p, states, eps=None, batch=128):
     return out
 
 
-def explain_by_relu_flips(p, states, actions, advantages, critic_target, beta, scale, got_flat, g_ref, eps=None):
+def explain_by_relu_flips(p, states, actions, advantages, critic_target, beta, scale, got_flat, g_ref, eps=None, max_flips=32):
     """Compares a float32 gradient (flat vector) with the float64 one up to the ReLU decisions float32 cannot be held to.
     A sample's pre-activation within round-off of zero may fall on either side in float32; its derivative mask then flips and the
     gradient moves by that element's whole contribution -- 1e-3 of a block's largest entry is typical at ~1000 samples -- although
     nothing is wrong.  For every ambiguous element j (relu_ambiguous) the exact gradient change D_j of flipping it is computed from
-    the one sample it belongs to; got - ref is then fitted by sum_j s_j D_j (least squares; elements of one conv1 pixel shared by an
-    env's agents give proportional columns, so single coefficients are not unique).  Returns (residual as a dict of blocks, the
-    coefficients s, the ambiguous list): a correct float32 gradient leaves a residual at float32 level."""
+    the one sample it belongs to.
+
+    A flip HAPPENED or it did not: got - ref must be the sum of D_j over a small SET of candidates, every coefficient exactly 1
+    (round 5; until then a least-squares fit with free real coefficients, which could absorb part of a genuine error lying in the
+    span of a few hundred columns).  The set is built greedily -- the candidate whose whole effect takes most off the residual
+    (every block weighted by its own largest reference entry), as long as taking it removes at least half of its own squared norm,
+    i.e. the residual really contains that column once and not 0.4 of it -- and nothing is ever fitted.  An env's ten agent
+    images share their conv pre-activations, so one float32 decision of the device's shared trunk is up to ten candidates here.
+
+    Returns (residual = got - ref - sum_{j in used} D_j as a dict of blocks, the 0/1 vector `used` over the candidates, the
+    candidate list): a correct float32 gradient leaves a residual at float32 level with a handful of candidates used."""
     N = states.shape[0]
     amb = relu_ambiguous(p, states, eps)
     r = got_flat.astype(np.float64) - flatten_params(g_ref)
@@ -255,16 +263,26 @@ def explain_by_relu_flips(p, states, actions, advantages, critic_target, beta, s
         m[layer].reshape(-1)[idx] ^= True
         cols.append((flatten_params(_conv_backward(p, c, mu, sigma, dmu, dsigma, dvs, m, scale)) - base) / N)
         m[layer].reshape(-1)[idx] ^= True
-    A = np.stack(cols, axis=1)
-    keep = np.abs(A).max(axis=0) > 0          # an element without upstream gradient cannot be seen either way
-    coef = np.zeros(A.shape[1])
-    if keep.any():
-        # every block counts relative to its own largest entry (the blocks' scales differ by 10^4, and the comparison that follows is
-        # per block); normal equations: A is (2.2 M x k) with k ~ 100, its Gram matrix is small
-        w = flatten_params({n: np.full(np.shape(g_ref[n]), 1.0 / max(np.abs(g_ref[n]).max(), 1e-300)) for n, _ in CONV_PARAM_SHAPES})
-        Ak = A[:, keep] * w[:, None]
-        coef[keep] = np.linalg.lstsq(Ak.T @ Ak, Ak.T @ (r * w), rcond=1e-10)[0]
-    return unflatten_params(r - A @ coef), coef, amb
+    # every block counts relative to its own largest entry (the blocks' scales differ by 10^4, and the comparison that follows is
+    # per block)
+    w = flatten_params({n: np.full(np.shape(g_ref[n]), 1.0 / max(np.abs(g_ref[n]).max(), 1e-300)) for n, _ in CONV_PARAM_SHAPES})
+    A = np.stack(cols, axis=1) * w[:, None]
+    rw = r * w
+    norm2 = (A * A).sum(axis=0)
+    used = np.zeros(A.shape[1])
+    free = norm2 > 0                          # an element without upstream gradient cannot be seen either way
+    for _ in range(max_flips):
+        if not free.any():
+            break
+        gain = 2.0 * (A.T @ rw) - norm2       # ||rw||^2 - ||rw - D_j||^2
+        gain[~free] = -np.inf
+        j = int(np.argmax(gain))
+        if not gain[j] > 0.5 * norm2[j]:      # <r, D_j> > 0.75 |D_j|^2: the column is in the residual about once
+            break
+        used[j] = 1.0
+        free[j] = False
+        rw = rw - A[:, j]
+    return unflatten_params(rw / w), used, amb
 
 
 def clip_by_global_norm(grads_flat, clip_norm):

@@ -53,27 +53,40 @@ def _observations(eng, E, regime, rng):
     return lb, ab, pos
 
 
+RAW_BOUND = 5e-3      # of a block's largest entry: what ONE flipped ReLU derivative of one sample can move at >= 600 samples (measured
+                      # 4e-4 .. 1.8e-3 on conv1_w); anything above is an error whatever the explainer says
+MAX_FLIPS = 32        # candidates that may be used: one float32 decision of the device's shared trunk is up to ten agent-samples here
+
+
 def _check_grads(got_flat, ref, p, states, act, adv, y, tol=2e-5, tag=""):
     """Every gradient block within tol of its largest entry -- ten times tighter than tests/test_gpu_net.py's bar -- AFTER the ReLU
     decisions float32 cannot be held to are accounted for: among ~10^7 pre-activations of a 1 000-sample batch a handful sit within
     float32 round-off of zero, the device may put them on the other side, and each such element moves whole gradient entries (the
-    one-hot rows of conv1_w by 1e-3 of the block's maximum).  oracle.nets.explain_by_relu_flips fits got - ref with the exact
-    per-element effects of the candidates (|z| < 2e-6 of the layer's range); what is left must be float32 rounding."""
+    one-hot rows of conv1_w by 1e-3 of the block's maximum).  oracle.nets.explain_by_relu_flips subtracts the EXACT effect of a small
+    set of such candidates (|z| < 2e-6 of the layer's range), each taken whole or not at all -- nothing is fitted (round 5; VERDICT
+    r4 #6 / advisor r4: the least-squares fit over hundreds of free coefficients could have absorbed a genuine error); what is left
+    must be float32 rounding.  The raw difference is bounded on its own."""
     got = NN.unflatten_params(got_flat.astype(np.float64))
     raw = {}
     for name, _ in NN.CONV_PARAM_SHAPES:
         scale = np.abs(ref[name]).max()
         assert scale > 0, (tag, name)
         raw[name] = np.abs(got[name] - ref[name]).max() / scale
+    assert max(raw.values()) < RAW_BOUND, (tag, raw)
     if max(raw.values()) < tol:
+        print("%s: raw worst %.1e (%s): no ReLU decision differs" % (tag, max(raw.values()), max(raw, key=raw.get)))
         return
-    res, coef, amb = NN.explain_by_relu_flips(p, states, act.astype(np.float64), adv.astype(np.float64), y.astype(np.float64), 0.02, 1000.0,
-                                              got_flat, ref)
+    res, used, amb = NN.explain_by_relu_flips(p, states, act.astype(np.float64), adv.astype(np.float64), y.astype(np.float64), 0.02, 1000.0,
+                                              got_flat, ref, max_flips=MAX_FLIPS)
     left = {k: np.abs(res[k]).max() / np.abs(ref[k]).max() for k in res}
-    print("%s: raw worst %.1e (%s); %d ambiguous ReLU inputs, %d used, residual worst %.1e" %
-          (tag, max(raw.values()), max(raw, key=raw.get), len(amb), int((np.abs(coef) > 0.02).sum()), max(left.values())))
+    taken = [(amb[i][0], amb[i][1], amb[i][2]) for i in np.flatnonzero(used)]
+    print("%s: raw worst %.1e (%s); %d ambiguous ReLU inputs, %d taken whole (coefficient 1) %s, residual worst %.1e" %
+          (tag, max(raw.values()), max(raw, key=raw.get), len(amb), len(taken), taken[:12], max(left.values())))
     assert 0 < len(amb) < 600, (tag, len(amb))
-    assert np.abs(coef).max() < 1.5, (tag, coef)
+    assert set(np.unique(used)) <= {0.0, 1.0} and 0 < len(taken) <= MAX_FLIPS, (tag, taken)
+    # the candidates taken are few PHYSICAL decisions: elements of the env-level trunk come as (up to) the env's ten agent-samples
+    physical = {(s // 10 if layer in ("a1", "a2", "a3") else s, layer, idx) for s, layer, idx in taken}
+    assert len(physical) <= 8, (tag, sorted(physical))
     bad = {k: v for k, v in left.items() if not v < tol}
     assert not bad, (tag, bad, raw)
 
@@ -118,16 +131,28 @@ def test_forward_and_gradients_match_the_oracle_above_one_row_tile(E, regime):
     eng.close()
 
 
-def test_rollout_gradient_matches_the_oracle_at_64_envs():
+@pytest.mark.parametrize("regime", ["rim", "interior"])
+def test_rollout_gradient_matches_the_oracle_at_64_envs(regime):
     """grl_net_rollout(T = 3) + grl_net_train_rollout_grads at 64 envs (1 920 samples, chunks of 500: four per step, the
     rollout-resident activations in use) against the oracle's pieces: the stored observations, raw actions, returns and
     advantages of the rollout fed to the float64 loss / gradient of the same parameters (paac.py:360-387: time-major
-    flatten, adv / scale, mean over T * B)."""
+    flatten, adv / scale, mean over T * B).  interior (round 5): the agents start inside the observation box, near the swarm -- where
+    a policy takes them within 100 updates (profiles/r04_training_geometry.json) -- so every step of the rollout runs 3 x 3 slot
+    rectangles, 5 x 5 supports and a full union mask through the resident-activation path."""
     from goldsrl import _ffi, _ffi_net
     E, T = 64, 3
     B = E * 10
     eng = _ffi.Engine(_ffi.ENV_SWARM, E, seed=33)
     eng.reset()
+    if regime == "interior":
+        rng = np.random.RandomState(5)
+        x = eng.get_state("SWARM_X")
+        xa = np.empty((E, 10, 2))
+        xa[:, :, 0] = x[:, :, 0].mean(axis=1)[:, None] + rng.uniform(-1.2, 0.0, size=(E, 10))
+        xa[:, :, 1] = rng.uniform(1.5, 4.3, size=(E, 10))
+        eng.set_state("SWARM_XA", xa)
+        eng.observe()
+        eng.wait()
     flat, p = _biased_params(9)
     net = _ffi_net.ConvNet(eng, max_chunk_samples=500)
     net.set_params(flat)
@@ -136,6 +161,8 @@ def test_rollout_gradient_matches_the_oracle_at_64_envs():
     lb = net.read_rollout("locust_bins", (T, E, 80, 2), np.uint8)
     ab = net.read_rollout("agent_bins", (T, E, 10, 2), np.uint8)
     ps = net.read_rollout("positions", (T, E, 10, 2), np.uint8)
+    inside = ((ps.astype(int) >= 8) & (ps.astype(int) <= 75)).all(axis=3).mean()
+    assert inside > 0.95 if regime == "interior" else inside < 0.9, (regime, inside)      # the premise of the case
     acts = net.read_rollout("actions", (T, B, 2)); vals = net.read_rollout("values", (T, B)); rews = net.read_rollout("rewards", (T, B))
     yy = net.read_rollout("y", (T, B)); adv = net.read_rollout("adv", (T, B)); boot = net.read_rollout("boot", (B,))
     states = np.concatenate([_states(lb[t], ab[t], ps[t]) for t in range(T)])
@@ -148,7 +175,7 @@ def test_rollout_gradient_matches_the_oracle_at_64_envs():
                                                 yy.reshape(-1).astype(np.float64), 0.02, 1000.0)
     st = net.train_rollout_grads()
     np.testing.assert_allclose(st["loss"], loss, rtol=1e-4)
-    _check_grads(net.get_grads(), g, p, states, acts.reshape(-1, 2), adv.reshape(-1), yy.reshape(-1), tag="rollout")
+    _check_grads(net.get_grads(), g, p, states, acts.reshape(-1, 2), adv.reshape(-1), yy.reshape(-1), tag="rollout-" + regime)
     net.close()
     eng.close()
 

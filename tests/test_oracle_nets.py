@@ -94,3 +94,61 @@ def test_flat_gradients_match_finite_differences():
     for nm, vals in num.items():
         for idx, gv in vals:
             assert abs(g[nm][idx] - gv) <= 2e-3 * abs(gv) + 1e-6, (nm, idx, g[nm][idx], gv)
+
+
+def test_the_relu_flip_explainer_takes_a_flip_whole_or_not_at_all():
+    """oracle.nets.explain_by_relu_flips (what tests/test_gpu_net_tiles.py holds the device's gradient against at 640-1 920 samples)
+    must explain a REAL flipped ReLU derivative -- and nothing else: a gradient that contains 0.4 of a candidate's effect, or a
+    candidate's effect plus a genuine error, keeps its residual (advisor r4: the free least-squares fit it
+    replaces could absorb such things)."""
+    p = NN.conv_init(seed=5)
+    rs = np.random.RandomState(1)
+    for k in p:
+        if k.endswith("_b"):
+            p[k] = rs.normal(size=p[k].shape) * 0.05
+    s, a, adv, y = _tiny_batch(n=6, seed=3)
+    beta, scale = 0.02, 1000.0
+    eps = {k: 2e-3 for k in NN.RELU_LAYERS}
+    eps["a1"] = 0.0      # (conv1 has ~10^4 elements per sample within any useful eps of zero: the dense layers give enough candidates)
+    eps["a2"] = eps["a3"] = 2e-4
+    amb = NN.relu_ambiguous(p, s, eps)
+    assert 3 <= len(amb) < 400, len(amb)
+    _, _, _, g, _ = NN.conv_loss_and_grads(p, s, a, adv, y, beta, scale)
+    ref_flat = NN.flatten_params(g)
+    # a candidate with a visible effect
+    sizes = {"a1": 20 * 20 * 32, "a2": 9 * 9 * 64, "a3": 7 * 7 * 64, "d1": 512, "d2": 256, "p1": 512, "v1": 512, "v2": 256}
+    pick = None
+    for j, (smp, layer, idx, _) in enumerate(amb):
+        gf = NN.conv_loss_and_grads(p, s, a, adv, y, beta, scale, flip=[(layer, smp * sizes[layer] + idx)])[3]
+        d = NN.flatten_params(gf) - ref_flat
+        rel = max(np.abs(NN.unflatten_params(d)[k]).max() / np.abs(g[k]).max() for k in g)
+        if rel > 1e-3:
+            pick = (j, d)
+            break
+    assert pick is not None
+    j, d = pick
+    noise = 1.0 + 1e-7 * rs.normal(size=ref_flat.size)
+
+    def worst(res):
+        return max(np.abs(res[k]).max() / np.abs(g[k]).max() for k in res)
+    # (1) the flip as it happens: taken whole, residual at float32 level
+    got = ((ref_flat + d) * noise).astype(np.float32)
+    res, used, amb2 = NN.explain_by_relu_flips(p, s, a, adv, y, beta, scale, got, g, eps=eps)
+    assert len(amb2) == len(amb) and used[j] == 1.0 and used.sum() <= 3 and worst(res) < 2e-5, (used.nonzero(), worst(res))
+    # (2) no flip: nothing taken
+    res, used, _ = NN.explain_by_relu_flips(p, s, a, adv, y, beta, scale, (ref_flat * noise).astype(np.float32), g, eps=eps)
+    assert used.sum() == 0 and worst(res) < 2e-5
+    # (3) 0.4 of a flip's effect is an error, not a flip: the residual stays
+    res, used, _ = NN.explain_by_relu_flips(p, s, a, adv, y, beta, scale, (ref_flat + 0.4 * d).astype(np.float32), g, eps=eps)
+    assert worst(res) > 1e-4, (used.nonzero(), worst(res))
+    # (4) a flip plus a genuine error in one block: the flip is explained, the error is not
+    e = np.zeros_like(ref_flat)
+    off = 0
+    for name, shape in NN.CONV_PARAM_SHAPES:
+        sz = int(np.prod(shape))
+        if name == "dense2_w":
+            e[off:off + sz] = 1e-3 * np.abs(g[name]).max() * rs.normal(size=sz)
+        off += sz
+    res, used, _ = NN.explain_by_relu_flips(p, s, a, adv, y, beta, scale, (ref_flat + d + e).astype(np.float32), g, eps=eps)
+    left = {k: np.abs(res[k]).max() / np.abs(g[k]).max() for k in res}
+    assert used[j] == 1.0 and left["dense2_w"] > 5e-4, (used.nonzero(), left)
