@@ -663,6 +663,44 @@ def test_patch_support_masks_change_nothing_but_the_work(monkeypatch):
     eng.close()
 
 
+@pytest.mark.parametrize("knob", ["GRL_PATCH_WGRAD_PAIR"])
+def test_a_tile_shape_changes_nothing_but_the_work(monkeypatch, knob):
+    """A/B switches that change which WORKGROUP computes an output element, not the sum it is: the same K-tiles of 32 rows in the same
+    order, so the whole gradient must be EQUAL bit for bit.  GRL_PATCH_WGRAD_PAIR (round 5): dense1's patch weight gradient on 128 x 128
+    tiles made of two live patch pixels of the slice's support union (PatchRowsPair, net_gemm.h) against the 64 x 128 per-pixel tiles.
+    3 000 samples in two chunks: slices of 1 024 sorted rows with odd and even numbers of live pixels (rim agents with 1 x 1 .. 3 x 3
+    slot rectangles, interior agents with full 5 x 5 supports, agents outside the box), ragged last slices."""
+    from goldsrl import _ffi, _ffi_net
+    E = 300
+    eng = _ffi.Engine(_ffi.ENV_SWARM, E, seed=3)
+    eng.reset()
+    rng = np.random.RandomState(25)
+    edge = [0, 1, 2, 3, 5, 8, 75, 79, 80, 82, 83]
+    lb = rng.randint(0, 84, size=(E, 80, 2)).astype(np.uint8)
+    pos = np.zeros((E, 10, 2), np.uint8)
+    for e in range(E):
+        for a in range(10):
+            kind = (a + e) % 4
+            pos[e, a] = ((rng.choice(edge), rng.choice(edge)) if kind == 0 else (rng.randint(0, 84), rng.choice(edge)) if kind == 1
+                         else (rng.choice(edge), rng.randint(0, 84)) if kind == 2 else (rng.randint(12, 70), rng.randint(12, 70)))
+    ab = pos.copy()
+    ab[::11, :3] = 255
+    act, adv, y = _train_inputs(E, seed=26)
+    flat = _ffi_net.glorot_uniform_flat(seed=7)
+    res = {}
+    for mode in ("on", "off"):
+        monkeypatch.setenv(knob, mode)      # read when the net is created
+        net = _ffi_net.ConvNet(eng, max_chunk_samples=1500)
+        net.set_params(flat)
+        stats = net.train_obs(lb, ab, pos, act, adv, y, lr=0.0, apply_update=False)
+        res[mode] = (stats, net.get_grads().copy())
+        net.close()
+    assert res["on"][0] == res["off"][0]
+    assert np.isfinite(res["on"][1]).all() and np.abs(res["on"][1]).max() > 0
+    assert np.array_equal(res["on"][1], res["off"][1])
+    eng.close()
+
+
 @pytest.mark.parametrize("knob,modes", [("GRL_NET_EXPAND3", ("gather", "prod")), ("GRL_NET_ACC1", ("on", "off"))])
 def test_two_forms_of_the_same_layer_agree_at_the_float32_level(monkeypatch, knob, modes):
     """Two A/B switches that change the ORDER of a sum, not its terms, so heads and gradients agree at the float32 level, not bitwise.
