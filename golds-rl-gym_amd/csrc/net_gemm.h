@@ -642,6 +642,21 @@ struct PatchRowsPair : PatchRows {
     }
 };
 
+// The same idea on gemm_rowk's N axis (dense1's patch data gradient, mode 1: the output columns are the patch): grid x = t takes the
+// (2t)-th and (2t+1)-th set bit of the 128-row tile's support union, a 128 x 128 tile on eight waves (wave column wn = pixel half)
+// instead of 256 x 64 per pixel.  Same K-tiles in the same order per output element: bit-identical g3p.
+struct PatchRowsPairN : PatchRows {
+    static constexpr bool kPairN = true;
+    __device__ __forceinline__ int2 npair(int m0, int t) const {      // BM = 128
+        unsigned zm = tmask ? tmask[m0 >> 7] : 0x1FFFFFFu;
+        for (int s = 0; s < 2 * t; ++s) zm &= zm - 1u;
+        if (!zm) return make_int2(-1, -1);
+        const int p0 = __ffs(zm) - 1;
+        zm &= zm - 1u;
+        return make_int2(p0, zm ? __ffs(zm) - 1 : -1);
+    }
+};
+
 // conv2's per-agent corrections as ONE GEMM (net_shared.inc, forward): row = agent (sorted by the parity class of its conv1 window,
 // perm[slot] = sample or -1, tilegroup[slot >> 8] = class or -1), K = 4 conv1 candidates x 32 channels of (a1_a - a1_sh), N = 9
 // canonical conv2 outputs x 64 channels against the class's own 576-row block of Bt.
@@ -1121,6 +1136,8 @@ template <class T, class = void> struct ag_has_n_ok : std::false_type {};
 template <class T> struct ag_has_n_ok<T, std::void_t<decltype(std::declval<const T &>().n_ok(0, 0))>> : std::true_type {};
 template <class T, class = void> struct ag_has_i_ok : std::false_type {};
 template <class T> struct ag_has_i_ok<T, std::void_t<decltype(std::declval<const T &>().i_ok(0, 0))>> : std::true_type {};
+template <class T, class = void> struct ag_pair_n : std::false_type {};
+template <class T> struct ag_pair_n<T, std::void_t<decltype(T::kPairN)>> : std::bool_constant<T::kPairN> {};
 template <class T, class = void> struct ag_pair_i : std::false_type {};
 template <class T> struct ag_pair_i<T, std::void_t<decltype(T::kPairI)>> : std::bool_constant<T::kPairI> {};
 
@@ -1172,7 +1189,13 @@ __global__ __launch_bounds__(64 * WGM * WGN, ACC1 ? (WGM * WGN == 8 ? 6 : 4) : W
     }
     const int m0 = by * BM, n0 = bx * BN;
     if (!ag.tile_active(m0)) return;     // block-uniform (padding tiles of the group-sorted layouts)
-    if constexpr (ag_has_n_ok<AG>::value) {      // a column tile that is zero for every row of the tile is neither computed nor stored:
+    constexpr bool PAIRN = ag_pair_n<AG>::value;      // the N tile is two independent 64-column runs (PatchRowsPairN)
+    int2 pp = make_int2(0, 0);
+    if constexpr (PAIRN) {
+        static_assert(!PAIRN || (BM == 128 && BN == 128 && WGN == 2 && 64 * WGM * WGN == 512), "128 x 128 on eight waves: a wave column per pixel");
+        pp = ag.npair(m0, bx);
+        if (pp.x < 0) return;                    // fewer live pixels than this tile's first
+    } else if constexpr (ag_has_n_ok<AG>::value) {      // a column tile that is zero for every row of the tile is neither computed nor stored:
         if (!ag.n_ok(m0, n0)) return;            // its consumer knows the same masks (agent_dz3_kernel)
     }
     const int M = ag.rows, K = ag.K();
@@ -1193,7 +1216,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, ACC1 ? (WGM * WGN == 8 ? 6 : 4) : W
         ayx[i] = (iy0 << 16) | (ix0 & 0xFFFF);
     }
     static_assert(NB == 1 || NB == 2 || NB == 4, "B tile of 1, 2 or 4 passes");
-    const float *brow0 = Bt + (long)(ag.bn(n0, m0) + trow) * ldb + tk4;
+    const float *brow0 = Bt + (long)(ag.bn(PAIRN ? pp.x * 64 : n0, m0) + trow) * ldb + tk4;
+    // second pass of B rows (RPP further down; PAIRN: the second pixel's rows -- the first one's again where the tile has only one)
+    const float *brow1 = PAIRN ? Bt + (long)(ag.bn(max(pp.y, pp.x) * 64, m0) + trow) * ldb + tk4 : brow0 + (long)RPP * ldb;
 
     float4 ra[NA];
     float4 rb0 = make_float4(0.f, 0.f, 0.f, 0.f), rb1 = rb0, rb2 = rb0, rb3 = rb0;
@@ -1213,7 +1238,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, ACC1 ? (WGM * WGN == 8 ? 6 : 4) : W
         /* named scalars, not an array: an array here is "promoted" to LDS by the compiler */             \
         const int bko = ag_bk(ag, wctx, m0, (kt_) * BK);                                                             \
         rb0 = *reinterpret_cast<const float4 *>(brow0 + bko);                                              \
-        if (NB > 1) rb1 = *reinterpret_cast<const float4 *>(brow0 + (long)RPP * ldb + bko);                \
+        if (NB > 1) rb1 = *reinterpret_cast<const float4 *>(brow1 + bko);                                  \
         if (NB > 2) rb2 = *reinterpret_cast<const float4 *>(brow0 + (long)2 * RPP * ldb + bko);            \
         if (NB > 2) rb3 = *reinterpret_cast<const float4 *>(brow0 + (long)3 * RPP * ldb + bko);            \
     }
@@ -1375,7 +1400,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, ACC1 ? (WGM * WGN == 8 ? 6 : 4) : W
     }
     // C/D map of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + reg.  Two passes: all of the epilogue's loads, then
     // the stores (see the epilogue structs).
-    const int erow = m0 + wm * WM + 4 * kg, ecol = n0 + wn * WN + l16;
+    // (PAIRN: wave column wn stores the tile's wn-th pixel; a missing second pixel puts the columns past N: nothing is stored)
+    const int ecolbase = PAIRN ? ((wn == 0 ? pp.x : pp.y) < 0 ? N : (wn == 0 ? pp.x : pp.y) * 64) : n0 + wn * WN;
+    const int erow = m0 + wm * WM + 4 * kg, ecol = ecolbase + l16;
     int rax[TM][4];
     float eax[TM][TN][4];
     bool out_of_range = false;
@@ -1385,7 +1412,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, ACC1 ? (WGM * WGN == 8 ? 6 : 4) : W
     for (int a = 0; a < TM; ++a)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            if constexpr (epi_row_bits<Epi>::value || epi_row_auxn<Epi>::value) rax[a][r] = epi.row_aux_n(min(erow + a * 16 + r, M - 1), n0 + wn * WN);
+            if constexpr (epi_row_bits<Epi>::value || epi_row_auxn<Epi>::value) rax[a][r] = epi.row_aux_n(min(erow + a * 16 + r, M - 1), ecolbase);
             else rax[a][r] = epi.row_aux(min(erow + a * 16 + r, M - 1));
         }
 #pragma unroll
@@ -1437,7 +1464,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, ACC1 ? (WGM * WGN == 8 ? 6 : 4) : W
                     w |= ((bal >> (16 * kg)) & 0xFFFFull) << (16 * b);
                 }
                 const int row = erow + a * 16 + r;
-                if (l16 == 0 && row < M) epi.store_bits(row, n0 + wn * WN, w, rax[a][r]);
+                if (l16 == 0 && row < M) epi.store_bits(row, ecolbase, w, rax[a][r]);
             }
     }
 #undef GRL_LOAD_TILE
