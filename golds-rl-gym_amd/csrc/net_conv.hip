@@ -153,6 +153,10 @@ struct grl_net : NetLane {
     int trunk_skip;            // 1: conv2's forward / weight gradient / transposed convolution run over the rows the env's bins reach (GRL_TRUNK_SKIP=off: all rows)
     int patch_skip;            // 1: the dense1 patch GEMMs skip what the support masks say is zero (GRL_PATCH_SKIP=off: the plain 5x5 patch)
     int gemm_f32, range_fallback_on, range_fallbacks, range_bits_last, update_skipped_last;
+    // the way back: gemm_f32 was set BY a range violation (not by GRL_NET_GEMM=f32 / grl_net_set_gemm_f32), updates in a row whose
+    // largest |GEMM output| stayed below 65 504 / 4, how many of them take the net back (0: never), how often that happened
+    int f32_by_fallback, f32_clean_passes, range_return_k, range_returns;
+    float absmax_last;
     int loss_scale_on;         // per-pass power-of-two scale of the head gradients (net_train.inc); GRL_NET_LOSS_SCALE=off disables it
     int acc1;                  // gemm_rowk instances built with ACC1 use it (GRL_NET_ACC1=off: the two-accumulator form everywhere)
     int expand3_gather;        // conv3's per-agent corrections as a gather GEMM at the patch pixels (default; GRL_NET_EXPAND3=prod: slot products + expansion kernel)
@@ -999,6 +1003,9 @@ int grl_net_create(grl_handle *h, const grl_net_config *cfg, grl_net **out) {
         n->gemm_f32 = (gm && strcmp(gm, "f32") == 0) ? 1 : 0;                    // force the fp32-MFMA form from the start (tests, A/B)
         n->range_fallback_on = (rf && strcmp(rf, "off") == 0) ? 0 : 1;            // off: a range violation fails the call (GRL_E_RANGE) and nothing else
         n->range_fallbacks = 0; n->range_bits_last = 0; n->update_skipped_last = 0;
+        n->f32_by_fallback = 0; n->f32_clean_passes = 0; n->range_returns = 0; n->absmax_last = 0.f;
+        n->range_return_k = 4;
+        if (const char *rr = getenv("GRL_NET_RANGE_RETURN")) n->range_return_k = strcmp(rr, "off") == 0 ? 0 : std::max(0, atoi(rr));
         const char *psk = getenv("GRL_PATCH_SKIP");
         n->patch_skip = (psk && strcmp(psk, "off") == 0) ? 0 : 1;
         const char *tsk = getenv("GRL_TRUNK_SKIP");
@@ -1139,14 +1146,17 @@ static int range_flag_init(grl_net *n) {
     if (g_range_flag_dev[dev]) return GRL_OK;
     NET_HIP(n, hipSetDevice(dev));
     int *p = nullptr;
-    NET_HIP(n, hipMalloc((void **)&p, sizeof(int)));
-    NET_HIP(n, hipMemset(p, 0, sizeof(int)));
+    NET_HIP(n, hipMalloc((void **)&p, 2 * sizeof(int)));      // [0] the range flag, [1] the fp32 form's largest |output| (float bits)
+    NET_HIP(n, hipMemset(p, 0, 2 * sizeof(int)));
     NET_HIP(n, hipMemcpyToSymbol(HIP_SYMBOL(grl::g_gemm_range_flag), &p, sizeof(p)));      // this device's instance of the symbol
+    unsigned *pa = reinterpret_cast<unsigned *>(p + 1);
+    NET_HIP(n, hipMemcpyToSymbol(HIP_SYMBOL(grl::g_gemm_absmax), &pa, sizeof(pa)));
     (void)hipGetLastError();      // the symbol lookup may probe other ordinals and leave a stale error on this thread
     g_range_flag_dev[dev] = p;
     return GRL_OK;
 }
 static int *range_flag_ptr(grl_net *n) { return g_range_flag_dev[n->h->cfg.device_id]; }
+static unsigned *range_absmax_ptr(grl_net *n) { return reinterpret_cast<unsigned *>(g_range_flag_dev[n->h->cfg.device_id] + 1); }
 // flag bits: 1 = some GEMM output of the work since the last check left the fp16 range; 2 = that was already so when the last
 // rollout ended (rollout_range_mark_kernel), i.e. the rollout's own actions / values come from invalid operands
 static int range_check(grl_net *n, const char *where) {
@@ -1160,14 +1170,53 @@ static int range_check(grl_net *n, const char *where) {
                                                       "(include/goldsrl_net.h, Arithmetic); the results of this call are not valid");
 }
 
-// A pass that left the fp16 range: switch the net to the fp32-MFMA GEMMs (it stays there: grl_net_set_gemm_f32 switches back) and
-// tell the caller to run the work again.  Returns false when the fallback is off or the net already computes in fp32.
+// A pass that left the fp16 range: switch the net to the fp32-MFMA GEMMs and tell the caller to run the work again.  Returns false
+// when the fallback is off or the net already computes in fp32.  The net stays on the fp32 form until range_return_k updates in a
+// row stayed well inside the fp16 range (range_maybe_return, called where an update ends) or grl_net_set_gemm_f32(net, 0).
 static bool range_fall_back(grl_net *n) {
     if (!n->range_fallback_on || n->gemm_f32) return false;
     n->gemm_f32 = 1;
     n->range_fallbacks += 1;
+    n->f32_by_fallback = 1;
+    n->f32_clean_passes = 0;
+    (void)hipMemset(range_absmax_ptr(n), 0, sizeof(unsigned));
     (void)trunk_background(n);      // the background rows in the arithmetic the list GEMMs now use
     return true;
+}
+
+// End of an applied update on the fp32 form (stream drained): the largest |value| any gemm_rowk tile handed on since the last
+// update -- rollout, gradient step and the background rows of the NEW parameters; with RCCL the word was max-reduced beside the
+// range flag, and what came after the collective ran on identical parameters, so every rank reads the same number.  A spike is
+// transient: range_return_k clean updates in a row (below a quarter of the fp16 range: a margin of 4 against coming straight back)
+// take the net back to the three-product form, whose background rows are rebuilt; should THAT pass leave the range the net is back
+// on the fp32 form before anyone has used it.
+static int range_maybe_return(grl_net *n) {
+    if (!n->gemm_f32 || !n->f32_by_fallback || n->range_return_k <= 0) return GRL_OK;
+    unsigned bits = 0;
+    NET_HIP(n, hipMemcpy(&bits, range_absmax_ptr(n), sizeof(bits), hipMemcpyDeviceToHost));
+    NET_HIP(n, hipMemset(range_absmax_ptr(n), 0, sizeof(unsigned)));
+    float amax;
+    memcpy(&amax, &bits, sizeof(amax));
+    n->absmax_last = amax;
+    if (amax < kF16Max / 4.f) n->f32_clean_passes += 1;      // (inf and NaN compare false)
+    else n->f32_clean_passes = 0;
+    if (n->f32_clean_passes < n->range_return_k) return GRL_OK;
+    n->gemm_f32 = 0;
+    n->f32_by_fallback = 0;
+    n->f32_clean_passes = 0;
+    n->range_returns += 1;
+    int rc = trunk_background(n);
+    if (rc) return rc;
+    NET_HIP(n, hipStreamSynchronize(n->h->stream));
+    int flag = 0;
+    NET_HIP(n, hipMemcpy(&flag, range_flag_ptr(n), sizeof(int), hipMemcpyDeviceToHost));
+    if (flag) {
+        NET_HIP(n, hipMemset(range_flag_ptr(n), 0, sizeof(int)));
+        n->range_returns -= 1;
+        (void)range_fall_back(n);
+        NET_HIP(n, hipStreamSynchronize(n->h->stream));
+    }
+    return GRL_OK;
 }
 
 static int download_heads(grl_net *n, int B, float *mu_host, float *sigma_host, float *vs_host) {
@@ -1225,7 +1274,25 @@ int grl_net_set_gemm_f32(grl_net *n, int32_t on) {
     hipSetDevice(n->h->cfg.device_id);
     NET_HIP(n, hipStreamSynchronize(n->h->stream));
     n->gemm_f32 = on ? 1 : 0;
+    n->f32_by_fallback = 0;      // the caller's choice stands until the caller (or a range violation) changes it
+    n->f32_clean_passes = 0;
     return trunk_background(n);
+}
+
+int grl_net_range_return_info(grl_net *n, int32_t *returns_out, int32_t *clean_passes_out, int32_t *needed_out, float *absmax_last_out) {
+    if (!n) return GRL_E_INVALID;
+    if (returns_out) *returns_out = n->range_returns;
+    if (clean_passes_out) *clean_passes_out = n->f32_clean_passes;
+    if (needed_out) *needed_out = n->range_return_k;
+    if (absmax_last_out) *absmax_last_out = n->absmax_last;
+    return GRL_OK;
+}
+
+int grl_net_set_range_return(grl_net *n, int32_t clean_passes) {
+    if (!n || clean_passes < 0) return GRL_E_INVALID;
+    n->range_return_k = clean_passes;
+    n->f32_clean_passes = 0;
+    return GRL_OK;
 }
 
 static int read_activation_impl(grl_net *n, const char *which, float *host, size_t bytes);

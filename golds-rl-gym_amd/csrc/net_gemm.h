@@ -1076,6 +1076,10 @@ constexpr int kLdh = 32;
 // fp16 range (|v| > 65 504: the next split would turn it into inf, and ReLU's max would swallow the NaN that follows) raises this
 // sticky flag; the host reads it at its next synchronisation point and fails the call with GRL_E_RANGE (net_conv.hip: range_check).
 __device__ int *g_gemm_range_flag;      // -> one hipMalloc'd word per process, set when the first net is created
+// The way back from the fp32 form (round 5): while a net computes on it, every gemm_rowk tile also records the largest |value| it
+// hands on (float bits, compared as unsigned: one atomicMax per wave).  The host reads it at the end of an update; after a few
+// updates that stayed well inside the fp16 range the net returns to the fast form (net_train.inc, train_apply).
+__device__ unsigned *g_gemm_absmax;     // -> the word behind the flag
 constexpr float kF16Max = 65504.f;
 // wave layouts of the two large tile shapes (WGM x WGN waves; 4 x 2 and 8 x 1: eight waves with 32 x 64 wave tiles)
 constexpr int kW128M = 4, kW128N = 2, kW256M = 8, kW256N = 1;
@@ -1406,6 +1410,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, ACC1 ? (WGM * WGN == 8 ? 6 : 4) : W
     int rax[TM][4];
     float eax[TM][TN][4];
     bool out_of_range = false;
+    float amax = 0.f;
     // the loads are unconditional on clamped coordinates: a per-element predicate would wrap every load in its own
     // exec-mask block with a wait behind it
 #pragma unroll
@@ -1433,8 +1438,14 @@ __global__ __launch_bounds__(64 * WGM * WGN, ACC1 ? (WGM * WGN == 8 ? 6 : 4) : W
                 // range guard: what this tile hands to the next GEMM must be a finite fp16-range number (padding rows hold zeros)
                 const float gv = epi_add_aux<Epi>::value ? acc[a][b][r] + eax[a][b][r] : acc[a][b][r];
                 out_of_range |= !(fabsf(gv) <= kF16Max);
+                if constexpr (F32) amax = fmaxf(amax, fabsf(gv));
             }
-    if (!F32 && out_of_range) atomicOr(g_gemm_range_flag, 1);      // the fp32 form has no operand range to guard
+    if (!F32 && out_of_range) atomicOr(g_gemm_range_flag, 1);      // the fp32 form has no operand range to guard ...
+    if constexpr (F32) {                                            // ... it records how far inside the fp16 range it is instead
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+        if (lane == 0) atomicMax(g_gemm_absmax, __float_as_uint(amax));
+    }
     if constexpr (Epi::kColSum) {      // column sums of the stored values over this wave's rows, in a fixed order
 #pragma unroll
         for (int b = 0; b < TN; ++b) {

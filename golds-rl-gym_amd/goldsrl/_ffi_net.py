@@ -46,6 +46,8 @@ NET_SIGNATURES = {
     "grl_net_range_info": (C.c_int, [_P, _P, _P, _P]),
     "grl_net_host_times": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "grl_net_set_gemm_f32": (C.c_int, [_P, C.c_int32]),
+    "grl_net_range_return_info": (C.c_int, [_P, _P, _P, _P, _P]),
+    "grl_net_set_range_return": (C.c_int, [_P, C.c_int32]),
     "grl_net_profile_enable": (C.c_int, [_P, _I]),
     "grl_net_profile_read": (C.c_int, [_P, C.POINTER(_I), C.POINTER(C.c_float), C.POINTER(C.c_double)]),
     "grl_net_profile_read_tags": (C.c_int, [_P, _I, _P, _P, _P]),
@@ -276,6 +278,17 @@ class ConvNet(object):
 
     def set_gemm_f32(self, on=True):
         self._check(self.lib.grl_net_set_gemm_f32(self.n, 1 if on else 0))
+
+    def range_return_info(self):
+        """The way back from a range fallback: 'returns' = how often the net went back to the fp16 form, 'clean_passes' = clean updates
+        counted so far on the fp32 form, 'needed' = how many in a row it takes (0: never), 'absmax_last' = the largest |GEMM output|
+        the last decision saw."""
+        r, c, k, a = C.c_int32(), C.c_int32(), C.c_int32(), C.c_float()
+        self._check(self.lib.grl_net_range_return_info(self.n, C.byref(r), C.byref(c), C.byref(k), C.byref(a)))
+        return {"returns": r.value, "clean_passes": c.value, "needed": k.value, "absmax_last": a.value}
+
+    def set_range_return(self, clean_passes):
+        self._check(self.lib.grl_net_set_range_return(self.n, int(clean_passes)))
 
     def profile_enable(self, on=True):
         self._check(self.lib.grl_net_profile_enable(self.n, 1 if on else 0))

@@ -17,7 +17,7 @@
  * accumulator set, whose third weight plane holds h_w * 2^11; a larger weight takes the same way out as any other violation).  Nothing is clamped: every GEMM checks its output tile, and the first call that synchronises
  * after a violation (predict, train_*, apply_grads) does not return results computed from inf operands.  By default it switches the
  * net to the fp32 form of the same GEMM kernels (v_mfma_f32_16x16x4_f32, no range beyond float32's, an update of the headline configuration takes 0.50 s instead of 0.33: 1.5x, round 4; the net
- * stays there until grl_net_set_gemm_f32(net, 0)) and runs the work again: predict and train_obs in full; a gradient step over a
+ * stays there until four updates in a row stayed well inside the range -- grl_net_set_range_return below -- or grl_net_set_gemm_f32(net, 0)) and runs the work again: predict and train_obs in full; a gradient step over a
  * rollout runs again when only its backward pass overflowed, and is given up (GRL_OK, NaN statistics, update_skipped = 1 in
  * grl_net_range_info; parameters and Adam moments untouched) when the rollout's own forward passes did -- the next rollout is valid.
  * GRL_NET_RANGE_FALLBACK=off in the environment keeps the hard failure (GRL_E_RANGE); GRL_NET_GEMM=f32 starts on the fp32 form.
@@ -139,8 +139,19 @@ int grl_net_comm_destroy(grl_net *net);
  * often a range violation switched it there, *update_skipped_out = 1 when the LAST train_rollout* call gave its update up.  Any pointer
  * may be NULL. */
 int grl_net_range_info(grl_net *net, int32_t *gemm_f32_out, int32_t *fallbacks_out, int32_t *update_skipped_out);
-/* 1: compute every GEMM on the fp32 form; 0: back to the three-product fp16 form. */
+/* 1: compute every GEMM on the fp32 form (and stay there); 0: back to the three-product fp16 form. */
 int grl_net_set_gemm_f32(grl_net *net, int32_t on);
+/* The way back from a range fallback (round 5).  The reference's float32 graph (policy_v_network.py:14-59) has no operand range,
+ * so an activation spike costs it nothing; here it used to cost 1.5x for the rest of the run.  While a net computes on the fp32 form
+ * BECAUSE of a violation, every GEMM tile records the largest |value| it hands on; at the end of every applied update
+ * (grl_net_train_rollout, grl_net_train_obs with apply_update, grl_net_apply_grads) that maximum -- max-reduced over the ranks of an
+ * attached communicator, like the flag -- is compared with 65 504 / 4, and after `clean_passes` such updates in a row the net returns
+ * to the fp16 form (default 4; GRL_NET_RANGE_RETURN=n|off in the environment; 0 = never, the behaviour until round 4).  A form
+ * chosen with grl_net_set_gemm_f32 or GRL_NET_GEMM=f32 is never left on its own.
+ * grl_net_range_return_info: *returns_out = how often the net went back, *clean_passes_out = clean updates counted so far,
+ * *needed_out = how many it takes, *absmax_last_out = the maximum the last decision saw.  Any pointer may be NULL. */
+int grl_net_range_return_info(grl_net *net, int32_t *returns_out, int32_t *clean_passes_out, int32_t *needed_out, float *absmax_last_out);
+int grl_net_set_range_return(grl_net *net, int32_t clean_passes);
 
 /* What RCCL itself says about the attached communicator: ncclCommCount / ncclCommUserRank (0 / -1 without one), and the
  * gradient all-reduces so far: calls, summed and last duration in ms (HIP events around the collective on the handle's stream).

@@ -322,6 +322,128 @@ def test_a_rollout_that_left_the_range_gives_its_update_up_and_the_next_one_is_v
     net.close()
 
 
+def _spike_params(flat):
+    q = NN.unflatten_params(np.asarray(flat, np.float64))
+    q["conv2_b"] = q["conv2_b"] + 3.0e5          # relu(conv2) = 3e5: far outside the fp16 range
+    q["conv3_w"] = q["conv3_w"] * 1e-5
+    return NN.flatten_params(q).astype(np.float32)
+
+
+def test_a_transient_spike_costs_the_fp32_form_for_a_few_updates_only():
+    """The reference's float32 graph has no operand range, so an activation spike costs it nothing (policy_v_network.py:14-59).  Here a
+    spike moves the net to the fp32 form of the GEMMs (1.5x per update) -- and, since round 5, only for a while: every tile of that
+    form records the largest |value| it hands on, and after `needed` applied updates in a row that stayed below 65 504 / 4 the net is
+    back on the three-product form.  Checked: the counters update by update, the form after the K-th clean update,
+    a forward pass afterwards bit for bit that of a net that never left, an update that is faster again, a spike that persists
+    (outputs of 3e4: inside the fp16 range, above the margin) keeping the net where it is, and a form chosen by the caller staying."""
+    import time
+    from goldsrl import _ffi, _ffi_net
+    E, T = 2048, 3
+    eng = _ffi.Engine(_ffi.ENV_SWARM, E, seed=5)
+    eng.reset()
+    net = _ffi_net.ConvNet(eng)
+    flat = _ffi_net.glorot_uniform_flat(seed=4)
+    K = net.range_return_info()["needed"]
+    assert K == 4 and net.range_return_info()["returns"] == 0
+
+    def update():
+        net.rollout(T, 0)
+        t0 = time.perf_counter()
+        st = net.train_rollout(1e-5)
+        dt = time.perf_counter() - t0
+        assert np.isfinite(list(st.values())).all()
+        return dt
+
+    net.set_params(flat)
+    update()
+    t_fast = sorted(update() for _ in range(3))[1]
+    # the spike: one forward pass on parameters that push conv2's outputs to 3e5
+    good = net.get_params().copy()
+    net.set_params(_spike_params(good))
+    net.predict()
+    assert net.range_info()["gemm_f32"] and net.range_info()["fallbacks"] == 1
+    net.set_params(good)                              # ... and it is over
+    # the first update that ends after the fallback still sees the spike (the forward pass that was run again on the fp32 form is
+    # part of what it looks back on); the K after it are clean
+    t_f32 = [update()]
+    assert net.range_info()["gemm_f32"] and net.range_return_info()["clean_passes"] == 0 and net.range_return_info()["absmax_last"] > 65504
+    for k in range(K):
+        assert net.range_info()["gemm_f32"] and net.range_return_info()["clean_passes"] == k
+        t_f32.append(update())
+        ri = net.range_return_info()
+        assert 0 < ri["absmax_last"] < 65504 / 4, ri
+    assert not net.range_info()["gemm_f32"] and net.range_info()["fallbacks"] == 1
+    assert net.range_return_info()["returns"] == 1 and net.range_return_info()["clean_passes"] == 0
+    # back on the fast form: the forward pass of a net that never left it, and its speed
+    fresh = _ffi_net.ConvNet(eng)
+    fresh.set_params(net.get_params())
+    a, b = net.predict(), fresh.predict()
+    for k in a:
+        np.testing.assert_array_equal(a[k], b[k])
+    fresh.close()
+    t_back = sorted(update() for _ in range(3))[1]
+    print("gradient step: %.2f ms on the fp16 form, %.2f on the fp32 form, %.2f after the way back" % (t_fast * 1e3, sorted(t_f32)[1] * 1e3, t_back * 1e3))
+    assert t_back < 0.5 * (t_fast + sorted(t_f32)[1]), (t_fast, t_f32, t_back)
+    # a spike that stays: conv2 outputs of 3e4 never leave the fp16 range but sit above the margin -- no way back
+    q = NN.unflatten_params(net.get_params().astype(np.float64))
+    q["conv2_b"] = q["conv2_b"] + 3.0e4
+    q["conv3_w"] = q["conv3_w"] * 1e-4
+    hot = NN.flatten_params(q).astype(np.float32)
+    net.set_params(_spike_params(good)); net.predict()
+    assert net.range_info()["gemm_f32"] and net.range_info()["fallbacks"] == 2
+    net.set_params(hot)
+    for _ in range(K + 1):
+        net.rollout(T, 0)
+        net.train_rollout(0.0)
+        assert net.range_info()["gemm_f32"] and net.range_return_info()["clean_passes"] == 0
+        assert net.range_return_info()["absmax_last"] > 65504 / 4
+    # the caller's own choice is never undone
+    net.set_params(good)
+    net.set_gemm_f32(True)
+    for _ in range(K + 1):
+        update()
+    assert net.range_info()["gemm_f32"] and net.range_return_info()["returns"] == 1
+    net.close()
+    eng.close()
+
+
+def test_replicas_stay_bitwise_equal_while_one_of_them_is_on_the_fp32_form_and_comes_back():
+    """Two half-batch replicas exchanging gradients the host way (train_rollout_grads -> sum -> set_grads -> apply_grads(lr, 1/2): what
+    goldsrl.distributed does when RCCL cannot form a communicator, sharding as runners.py:18-19).  Replica 0 meets a spike on its own
+    data and computes on the fp32 form for K updates; replica 1 never leaves the fp16 form.  The parameters depend on the SUMMED
+    gradient only, so the replicas stay equal bit for bit through the fallback and the way back."""
+    from goldsrl import _ffi, _ffi_net
+    E, T, lr = 64, 3, 1e-4
+    flat = _ffi_net.glorot_uniform_flat(seed=4)
+    reps = []
+    for off in (0, E // 2):
+        eng = _ffi.Engine(_ffi.ENV_SWARM, E // 2, seed=5, env_id_offset=off)
+        eng.reset()
+        net = _ffi_net.ConvNet(eng)
+        net.set_params(flat)
+        reps.append((eng, net))
+    n0 = reps[0][1]
+    K = n0.range_return_info()["needed"]
+    n0.set_params(_spike_params(flat)); n0.predict(); n0.set_params(flat)
+    assert n0.range_info()["gemm_f32"] and not reps[1][1].range_info()["gemm_f32"]
+    for k in range(K + 3):
+        grads = []
+        for eng, net in reps:
+            net.rollout(T, 0)
+            net.train_rollout_grads()
+            grads.append(net.get_grads())
+        summed = grads[0] + grads[1]
+        for eng, net in reps:
+            net.set_grads(summed)
+            st = net.apply_grads(lr, 0.5)
+            assert np.isfinite(list(st.values())).all()
+        assert np.array_equal(reps[0][1].get_params(), reps[1][1].get_params()), k
+        assert n0.range_info()["gemm_f32"] == (k < K), (k, n0.range_info(), n0.range_return_info())      # update 0 still sees the spike
+    assert n0.range_return_info()["returns"] == 1 and reps[1][1].range_return_info()["returns"] == 0
+    for eng, net in reps:
+        net.close(); eng.close()
+
+
 def test_an_update_whose_new_background_row_leaves_the_range_is_applied_exactly_once():
     """train_apply() rebuilds the trunk's background rows from the UPDATED parameters with two fp16-form GEMMs before it reads the
     range flag.  If those overflow, the flag says nothing about the gradient pass Adam has just applied: the update must stand,
