@@ -163,7 +163,7 @@ struct grl_net : NetLane {
     int expand2_gemm, ctiles;  // conv2's per-agent corrections as a class-sorted GEMM (default) or the LDS-resident kernel (GRL_NET_EXPAND2=lds)
     float *w2corr;             // [4 classes][576][128] kernel slices of that GEMM, rebuilt with the transposes
     grl::HeadOff ho;           // offsets of the head / value parameters for this net's num_actions
-    int npad, ptiles, pslices, pslice_rows, pwgrad_xcd, pdgrad_xcd, pwgrad_pair, pdgrad_pair;
+    int npad, ptiles, pslices, pslice_rows, pwgrad_xcd, pdgrad_xcd, pwgrad_pair, pdgrad_pair, swgrad_pair, swgrad_chunks;
     int tn_wgs, tn_wgs_dense;  // workgroups a split-M weight-gradient launch aims at (slab count = tn_wgs / tiles)      // dense1 patch weight gradient: slice length and tile order (tuning knobs)
     size_t slab_floats, slab_used, slabb_floats, slabb_used;      // bump allocation of a chunk's partial-sum regions (net_train.inc)
     std::vector<grl::RJob> rq;      // the chunk's queued reductions (net_reduce.inc)
@@ -1023,6 +1023,10 @@ int grl_net_create(grl_handle *h, const grl_net_config *cfg, grl_net **out) {
     if (const char *e = getenv("GRL_PATCH_WGRAD_PAIR")) n->pwgrad_pair = strcmp(e, "off") != 0 && strcmp(e, "0") != 0;
     n->pdgrad_pair = 1;      // the same for the data gradient's N axis (PatchRowsPairN): 128 x 128 tiles on eight waves; off: 256 x 64 per pixel
     if (const char *e = getenv("GRL_PATCH_DGRAD_PAIR")) n->pdgrad_pair = strcmp(e, "off") != 0 && strcmp(e, "0") != 0;
+    n->swgrad_pair = 1;      // conv3's slot weight gradient on 128 x 64 tiles of two live taps (SlotGatherT3PPair); off: 64 x 64 per tap
+    if (const char *e = getenv("GRL_SLOT_WGRAD_PAIR")) n->swgrad_pair = strcmp(e, "off") != 0 && strcmp(e, "0") != 0;
+    n->swgrad_chunks = 0;    // tuning knob: row ranges of that launch (0: the default of the call site)
+    if (const char *e = getenv("GRL_SLOT_WGRAD_CHUNKS")) n->swgrad_chunks = std::max(0, atoi(e));
     n->pdgrad_xcd = 1;      // M tile per XCD (A fetched once): 40.6 -> 38.5 ms per update at 81 920-sample chunks; spread (0) was faster at 40 960
     n->tn_wgs = 1024; n->tn_wgs_dense = 512;
     if (const char *e = getenv("GRL_TN_WGS")) { const int v = atoi(e); if (v >= 256 && v <= 4096) n->tn_wgs = v; }

@@ -507,6 +507,22 @@ struct SlotGatherT3P {
 };
 
 
+// SlotGatherT3P for gemm_tn with 128-wide I tiles made of TWO LIVE taps of the row range (round 5; PatchRowsPair's idea on conv3's
+// slot weight gradient): the B tile (d2s rows) is staged once for two taps, half the workgroups and slab tiles.  I tile index i =
+// tap in this gather's numbering = bit 8 - i of zmask[z].
+struct SlotGatherT3PPair : SlotGatherT3P {
+    static constexpr bool kPairI = true;
+    __device__ __forceinline__ int2 pair(int z, int t) const {
+        unsigned zm = zmask ? zmask[z] & 0x1FFu : 0x1FFu, rev = 0;
+        for (int i = 0; i < 9; ++i) rev |= ((zm >> (8 - i)) & 1u) << i;
+        for (int s = 0; s < 2 * t; ++s) rev &= rev - 1u;
+        if (!rev) return make_int2(-1, -1);
+        const int p0 = __ffs(rev) - 1;
+        rev &= rev - 1u;
+        return make_int2(p0, rev ? __ffs(rev) - 1 : -1);
+    }
+};
+
 // conv3's per-agent corrections GATHERED at the patch pixels (round 4; replaces the slot-product tensor and its expansion kernel in
 // the forward pass).  Row = one (sample, patch pixel q) item some dense1 GEMM may read (net_patch.inc, wmask); k = (tap, ci):
 //     A[row][t * 64 + ci] = (a2_a - a2sh)[u = r + t][ci]   where the agent has touched conv2 pixel u, else 0,
@@ -1543,8 +1559,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void gemm_tn(AG ag, 
         if (!ag.i_ok(bz, i0)) return;            // that follows knows the same masks (patch_dw_reduce_kernel)
     }
 
+    // (PAIR: pp names two 64-column I tiles; a thread's four columns lie in one of them, so tap and validity are per thread)
     int toff, ty, tx;
-    ag.tap(PAIR ? 0 : i0, toff, ty, tx);   // the BM-wide column run lies inside one tap row (checked on the host)
+    ag.tap(PAIR ? (((int)(threadIdx.x % (BM / 4)) < 16 ? pp.x : max(pp.y, 0)) * 64) : i0, toff, ty, tx);   // the BM-wide (64-wide) column run lies inside one tap row (checked on the host)
 
     // this thread's part of a tile: rows NA*(tid/A4) .. +NA-1 (A), NB*(tid/B4) .. +NB-1 (B), columns 4*ca .. 4*ca+3 / 4*cb ..
     // LDS has 32 banks of 4 bytes: a store instruction is served 128 bytes (32 x 4-byte or 16 x 8-byte lanes) per pass.  With the
@@ -1562,7 +1579,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void gemm_tn(AG ag, 
     if (NB == 1) gb ^= ((cb >> 1) & 1) << 2;      // one row per thread, stored as (m, m+1) pairs after a lane exchange: see GRL_STORE_TILE
     const int ma = NA * ga, mb = NB * gb;
     // column offset of this thread's four A columns inside the row, and whether its half of a pixel pair exists
-    const int acol = PAIR ? ((ca < 16 ? pp.x : max(pp.y, 0)) * 64 + (ca & 15) * 4) : toff + ca * 4;
+    const int acol = PAIR ? toff + (ca & 15) * 4 : toff + ca * 4;
     const bool ahalf_ok = !PAIR || ca < 16 || pp.y >= 0;
     float4 ra[NA], rb[NB];
     unsigned vma = 0, vmb = 0;

@@ -785,12 +785,13 @@ def test_patch_support_masks_change_nothing_but_the_work(monkeypatch):
     eng.close()
 
 
-@pytest.mark.parametrize("knob", ["GRL_PATCH_WGRAD_PAIR", "GRL_PATCH_DGRAD_PAIR"])
+@pytest.mark.parametrize("knob", ["GRL_PATCH_WGRAD_PAIR", "GRL_PATCH_DGRAD_PAIR", "GRL_SLOT_WGRAD_PAIR"])
 def test_a_tile_shape_changes_nothing_but_the_work(monkeypatch, knob):
     """A/B switches that change which WORKGROUP computes an output element, not the sum it is: the same K-tiles of 32 rows in the same
     order, so the whole gradient must be EQUAL bit for bit.  GRL_PATCH_WGRAD_PAIR (round 5): dense1's patch weight gradient on 128 x 128
     tiles made of two live patch pixels of the slice's support union (PatchRowsPair, net_gemm.h) against the 64 x 128 per-pixel tiles;
-    GRL_PATCH_DGRAD_PAIR: the same on the data gradient's N axis (PatchRowsPairN: 128 x 128 on eight waves against 256 x 64).
+    GRL_PATCH_DGRAD_PAIR: the same on the data gradient's N axis (PatchRowsPairN: 128 x 128 on eight waves against 256 x 64);
+    GRL_SLOT_WGRAD_PAIR: conv3's slot weight gradient on 128 x 64 tiles of two live taps of the row range (SlotGatherT3PPair).
     3 000 samples in two chunks: slices of 1 024 sorted rows with odd and even numbers of live pixels (rim agents with 1 x 1 .. 3 x 3
     slot rectangles, interior agents with full 5 x 5 supports, agents outside the box), ragged last slices."""
     from goldsrl import _ffi, _ffi_net
