@@ -635,12 +635,12 @@ def test_gradient_paths_agree_at_tile_multiple_sizes():
             # mask, each moving the gradients of dense1 and of everything below it by one sample-unit's worth (observed
             # 3e-5 in dense1, up to 3e-4 in conv1_w, where the sum cancels most); layers above dense1 see no masks flip.
             # Round 2: conv2's per-agent corrections come out of an MFMA GEMM instead of an FMA chain (1.5e-8 apart, no sign
-            # differs: tools/cmp_expand2.py); on this seed that moves a few more near-zero ReLU inputs of conv3 / dense1 across
-            # zero -- 1.1e-4 in dense1 (3 elements), 1.45e-3 in conv1_w (tools/diag_paths.py prints both kernels side by side).
+            # differs: tools/cmp_expand2.py in the history of this repo, round 2); on this seed that moves a few more near-zero ReLU inputs of conv3 / dense1 across
+            # zero -- 1.1e-4 in dense1 (3 elements), 1.45e-3 in conv1_w (tools/diag_paths.py, round 3, printed both kernels side by side).
             # The statistic is "which handful of inputs sits within round-off of zero", so the bound is loose by nature.
             # Round 3: dense1's per-env part adds the background pixels' share as one term (net_shared.inc, union mask); d1 moves by
             # 3e-8 (no sign differs), and on this seed ONE ReLU input of v1 crosses zero: v1_b differs in one element by 7.8e-5 of the
-            # block's largest, and that sample's rank-1 share reaches dense2 and below at 1e-5 (tools/diag_union.py lists the blocks).
+            # block's largest, and that sample's rank-1 share reaches dense2 and below at 1e-5 (tools/diag_union.py, round 3, listed the blocks).
             tol = 3e-3 if name == "conv1_w" else (1e-3 if name.startswith(("conv", "dense1")) else 2e-4 if name.startswith(("dense2", "v1")) else 5e-6)
             assert err < tol, (name, err)
     for s in stats[:4]:
