@@ -696,6 +696,14 @@ struct CorrRows {
     __device__ __forceinline__ bool ok(int iy0, int, int, int) const { return iy0 >= 0; }
     __device__ __forceinline__ bool tile_ok(int, int) const { return true; }
     __device__ __forceinline__ bool tile_active(int m0) const { return tilegroup[m0 >> 8] >= 0; }
+    // A column tile is one canonical output j = (ry, rx).  A class whose window starts on an odd conv1 row (py = 1) reaches canonical
+    // rows 0..1 only, an even one rows 0..2 (ry = qy + (cy == 1 && py == 0): net_shared.inc), likewise the columns: 4, 6, 6 or 9 of the
+    // nine outputs exist for the class, the other blocks of its B are zeros and no agent of the class has a slot there -- those tiles
+    // are neither computed nor stored (round 5: 31 % of the launch, in every support regime).
+    __device__ __forceinline__ bool n_ok(int m0, int n0) const {
+        const int g = tilegroup[m0 >> 8], j = n0 >> 6, ry = j / 3, rx = j - ry * 3;
+        return ry < 3 - (g >> 1) && rx < 3 - (g & 1);
+    }
     __device__ __forceinline__ int bk(int k0, int) const { return k0; }
     __device__ __forceinline__ int bn(int n0, int m0) const { return n0 + tilegroup[m0 >> 8] * 576; }
 };
