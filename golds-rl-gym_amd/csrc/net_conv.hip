@@ -163,7 +163,7 @@ struct grl_net : NetLane {
     int expand2_gemm, ctiles;  // conv2's per-agent corrections as a class-sorted GEMM (default) or the LDS-resident kernel (GRL_NET_EXPAND2=lds)
     float *w2corr;             // [4 classes][576][128] kernel slices of that GEMM, rebuilt with the transposes
     grl::HeadOff ho;           // offsets of the head / value parameters for this net's num_actions
-    int npad, ptiles, pslices, pslice_rows, pwgrad_xcd, pdgrad_xcd, pwgrad_pair, pdgrad_pair, swgrad_pair, swgrad_chunks;
+    int npad, ptiles, pslices, pslice_rows, pwgrad_xcd, pdgrad_xcd, pwgrad_pair, pdgrad_pair, swgrad_pair, swgrad_chunks, slots_xcd;
     int tn_wgs, tn_wgs_dense;  // workgroups a split-M weight-gradient launch aims at (slab count = tn_wgs / tiles)      // dense1 patch weight gradient: slice length and tile order (tuning knobs)
     size_t slab_floats, slab_used, slabb_floats, slabb_used;      // bump allocation of a chunk's partial-sum regions (net_train.inc)
     std::vector<grl::RJob> rq;      // the chunk's queued reductions (net_reduce.inc)
@@ -280,7 +280,7 @@ enum {
 };
 
 // every GEMM launch goes through these two: the net's arithmetic form picks the instantiation
-template <int BM, int BN, int WGM, int WGN, class AG, class Epi, bool XCD = true, bool FENCE = true, int NBUF = 1, bool ACC1 = false>
+template <int BM, int BN, int WGM, int WGN, class AG, class Epi, int XCD = 1, bool FENCE = true, int NBUF = 1, bool ACC1 = false>
 static void launch_rowk(grl_net *net, dim3 grid, hipStream_t st, AG ag, const float *Bt, int ldb, int N, Epi epi) {
     // ACC1, the one-accumulator form (net_gemm.h), buys a workgroup per CU without spilling on the eight-wave 128 x 128 tiles (92-98 -> 78
     // registers, six waves per SIMD) and the four-wave tiles of <= 128 x 64 (134-150 -> 94-116, four or five instead of three); the
@@ -1025,6 +1025,8 @@ int grl_net_create(grl_handle *h, const grl_net_config *cfg, grl_net **out) {
     if (const char *e = getenv("GRL_PATCH_DGRAD_PAIR")) n->pdgrad_pair = strcmp(e, "off") != 0 && strcmp(e, "0") != 0;
     n->swgrad_pair = 1;      // conv3's slot weight gradient on 128 x 64 tiles of two live taps (SlotGatherT3PPair); off: 64 x 64 per tap
     if (const char *e = getenv("GRL_SLOT_WGRAD_PAIR")) n->swgrad_pair = strcmp(e, "off") != 0 && strcmp(e, "0") != 0;
+    n->slots_xcd = 1;        // the sorted gather GEMMs keep a contiguous range of row tiles on one XCD (gemm_rowk, XCD_ORDER = 2); GRL_SLOTS_XCD=off: round-robin tiles
+    if (const char *e = getenv("GRL_SLOTS_XCD")) n->slots_xcd = strcmp(e, "off") != 0 && strcmp(e, "0") != 0;
     n->swgrad_chunks = 0;    // tuning knob: row ranges of that launch (0: the default of the call site)
     if (const char *e = getenv("GRL_SLOT_WGRAD_CHUNKS")) n->swgrad_chunks = std::max(0, atoi(e));
     n->pdgrad_xcd = 1;      // M tile per XCD (A fetched once): 40.6 -> 38.5 ms per update at 81 920-sample chunks; spread (0) was faster at 40 960

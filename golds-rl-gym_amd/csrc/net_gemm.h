@@ -559,6 +559,7 @@ struct SlotsToPatch {
     __device__ __forceinline__ bool tile_ok_c(unsigned c, int k0) const { return (c >> (k0 >> 6)) & 1u; }
     __device__ __forceinline__ int bk_c(unsigned, int k0) const { return k0; }
     __device__ __forceinline__ bool tile_active(int m0) const { return m0 < *rows_dev; }
+    __device__ __forceinline__ int live_rows() const { return *rows_dev; }      // gemm_rowk, XCD_ORDER = 2
     __device__ __forceinline__ int bn(int n0, int) const { return n0; }
 };
 
@@ -1177,7 +1178,7 @@ template <class T> struct ag_pair_i<T, std::void_t<decltype(T::kPairI)>> : std::
 // workgroups per CU either way, i.e. a 256- or 128-register budget.  (Round 4: the 128 x 64 four-wave instances sit at 134-150 registers,
 // three waves per SIMD; capped at 128 they spill 8-92 bytes per lane and the conv3 patch gather went 125 -> 193 us, conv2's class
 // corrections 113 -> 151, the conv3 row-list data gradient 62 -> 80 -- not adopted.)
-template <int BM, int BN, int WGM, int WGN, class AG, class Epi, bool XCD_ORDER = true, bool FENCE = true, bool F32 = false, int NBUF = 1, bool ACC1 = false>
+template <int BM, int BN, int WGM, int WGN, class AG, class Epi, int XCD_ORDER = 1, bool FENCE = true, bool F32 = false, int NBUF = 1, bool ACC1 = false>
 __global__ __launch_bounds__(64 * WGM * WGN, ACC1 ? (WGM * WGN == 8 ? 6 : 4) : WGM * WGN / 2) void gemm_rowk(AG ag, const float *__restrict__ Bt, int ldb, int N, Epi epi) {
     constexpr int BK = 32, LDH = kLdh, NT = 64 * WGM * WGN, RPP = NT / 8;          // RPP: tile rows staged per pass (8 threads per row)
     constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 16, TN = WN / 16;       // 16x16 MFMA tiles per wave
@@ -1206,8 +1207,17 @@ __global__ __launch_bounds__(64 * WGM * WGN, ACC1 ? (WGM * WGN == 8 ? 6 : 4) : W
     // M tiles stay spread over the XCDs).  A last partial run keeps the launch order.  XCD_ORDER = false keeps the launch
     // order everywhere.  (Also measured for the wide-N dense1 patch data gradient: runs of four M tiles per XCD walked N tile by N
     // tile, so that a group's weight slice is fetched once per run -- half the bytes again, no faster: 40.9-41.6 against 38.5 ms.)
+    // XCD_ORDER = 2 (one N tile, a live row count on the device: the sorted gathers): XCD x takes the CONTIGUOUS range of M tiles
+    // [x tpx, (x + 1) tpx), tpx = ceil(live tiles / 8), in order -- rows that are neighbours in the sorted order re-read the same
+    // operand lines (SlotsToPatch: a super-block's cells), which then stay in ONE 4 MB L2 instead of being fetched into all eight.
     int bx = blockIdx.x, by = blockIdx.y;
-    if (XCD_ORDER) {
+    if constexpr (XCD_ORDER == 2) {
+        const int nt = (ag.live_rows() + BM - 1) / BM, tpx = (nt + 7) >> 3, w = blockIdx.y;      // gridDim.x == 1, gridDim.y >= nt + 7
+        if ((w >> 3) >= tpx) return;
+        by = (w & 7) * tpx + (w >> 3);
+        if (by >= nt) return;
+    }
+    if (XCD_ORDER == 1) {
         const int nx = gridDim.x, L = by * nx + bx, g = L / (8 * nx);
         if ((g + 1) * 8 <= (int)gridDim.y) {
             const int l = L - g * 8 * nx;

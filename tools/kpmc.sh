@@ -1,12 +1,13 @@
 # Counters of ONE kernel family in a full PAAC update at 8 192 envs (single stream): duration, HBM-side fetch/write bytes, SQ busy/wait.
 # FETCH_SIZE and WRITE_SIZE do not fit one pass on gfx950 ("exceeds the capabilities of the hardware"), and a refused pass can hang: timeouts.
-# usage: bash tools/kpmc.sh NAME_REGEX [env assignments...]     (on the GPU box; every PMC group in its own pass)
+# usage: bash tools/kpmc.sh NAME_REGEX [env assignments | --bench-flags ...]     (on the GPU box; every PMC group in its own pass)
 set -e
 RX="$1"; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-for kv in "$@"; do export "$kv"; done
+EXTRA=""
+for kv in "$@"; do case "$kv" in --*) EXTRA="$EXTRA $kv";; *) export "$kv";; esac; done
 mkdir -p gpurun_out
-ARGS="bench.py --envs 8192 --steps 1 --warmup 0 --no-cpu-baseline --no-extras --single-stream"
+ARGS="bench.py --envs 8192 --steps 1 --warmup 0 --no-cpu-baseline --no-extras --single-stream $EXTRA"
 D=gpurun_out/kpmc
 rm -rf $D
 timeout -k 10 200 rocprofv3 --kernel-trace --kernel-include-regex "$RX" --pmc FETCH_SIZE --output-format csv -d $D/mem -- python3 $ARGS > $D.mem.log 2>&1
