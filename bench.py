@@ -53,7 +53,7 @@ MFMA_F16_PEAK_TFLOPS = 2516.6        # MI355X_MICROARCH.md: dense fp16 / bf16 ma
 # bf16 split with SIX products: peak 419.4, same kernels otherwise -- the fraction is not comparable across that change.)
 F16_PRODUCTS_PER_FP32 = 3
 MFMA_X3_PEAK_TFLOPS = MFMA_F16_PEAK_TFLOPS / F16_PRODUCTS_PER_FP32
-GEMM_TRAFFIC_FILE = "r04_gemm_traffic.json"   # PMC pass of the GEMM kernels (tools/run_prof.sh); refreshed per round
+GEMM_TRAFFIC_FILE = "r05_gemm_traffic.json"   # PMC pass of the GEMM kernels (tools/run_prof.sh); refreshed per round
 GEMM_TRAFFIC_FILE_INTERIOR = "r05_gemm_traffic_interior.json"   # the same pass on the interior_policy state distribution
 SHARD_ENVS = 4096                             # 32 768 / 8: one GPU's share of BASELINE's target shape (strong scaling)
 

@@ -494,6 +494,7 @@ struct SlotGatherT3P {
     __device__ __forceinline__ bool tile_ok_c(unsigned c, int k0) const { return (c >> (8 - (k0 >> 6))) & 1u; }
     __device__ __forceinline__ int bk_c(unsigned, int k0) const { return k0; }
     __device__ __forceinline__ bool tile_active(int m0) const { return m0 < *rows_dev; }
+    __device__ __forceinline__ int live_rows() const { return *rows_dev; }      // gemm_rowk, XCD_ORDER = 2
     __device__ __forceinline__ bool i_ok(int z, int i0) const { return !zmask || ((zmask[z] >> (8 - (i0 >> 6))) & 1u); }
     __device__ __forceinline__ int bn(int n0, int) const { return n0; }
     // gemm_tn: row handles are fetched one tile ahead of the data (ahandle / bhandle may load), rowh is arithmetic only
