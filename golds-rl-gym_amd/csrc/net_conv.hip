@@ -210,6 +210,12 @@ struct grl_net : NetLane {
     NetLane lanes[GRL_MAX_LANES];
     hipStream_t lane_stream[GRL_MAX_LANES];      // [0] = the handle's stream
     hipEvent_t ev_fork, ev_join[GRL_MAX_LANES];
+    // The index kernels of a forward pass that depend on the agents' positions alone (slot lists, class / slot / patch sorts: ~17 small
+    // launches, each a dependent step of a few us) run on a side stream per lane beside the env-level trunk (net_shared.inc,
+    // forward_conv12_shared): with one chunk per step -- 4 096 or 8 192 envs per GPU -- nothing else hides them (round 5).
+    hipStream_t side_stream[GRL_MAX_LANES];
+    hipEvent_t ev_side0[GRL_MAX_LANES], ev_side1[GRL_MAX_LANES];
+    int idx_side;
     int nlanes, cur_lane, last_lane;
 };
 
@@ -991,7 +997,8 @@ int grl_net_create(grl_handle *h, const grl_net_config *cfg, grl_net **out) {
     n->keep = nullptr; n->keep_slots = 0; n->param_version = 0; n->keep_version = -1;
     n->shared_trunk = (cfg->reserved & GRL_NET_F_PER_AGENT_TRUNK) ? 0 : 1;     // the plain per-agent evaluation is the A/B reference
     n->cur_lane = 0; n->last_lane = 0;
-    for (int k = 0; k < GRL_MAX_LANES; ++k) { n->lane_stream[k] = nullptr; n->ev_join[k] = nullptr; }
+    for (int k = 0; k < GRL_MAX_LANES; ++k) { n->lane_stream[k] = nullptr; n->ev_join[k] = nullptr; n->side_stream[k] = nullptr; n->ev_side0[k] = n->ev_side1[k] = nullptr; }
+    n->idx_side = 0;
     n->lane_stream[0] = h->stream; n->ev_fork = nullptr; n->nlanes = 1;
     const size_t c = n->chunk;
     n->ptiles = (int)((c + 255) / 256) + 9;
@@ -1058,6 +1065,17 @@ int grl_net_create(grl_handle *h, const grl_net_config *cfg, grl_net **out) {
         if (!ok) rc = nfail(n, GRL_E_HIP, "creating the lane streams/events failed");
     }
     if (rc == GRL_OK) n->nlanes = nlanes;
+    {   // the index side streams (not in the single-stream profiling configuration; GRL_NET_IDX_SIDE=off: everything on the lane's stream)
+        const char *e = getenv("GRL_NET_IDX_SIDE");
+        const bool want = !(cfg->reserved & GRL_NET_F_SINGLE_STREAM) && !(e && (!strcmp(e, "off") || !strcmp(e, "0")));
+        bool ok = want && rc == GRL_OK;
+        for (int k = 0; k < nlanes && ok; ++k)
+            ok = hipStreamCreateWithFlags(&n->side_stream[k], hipStreamNonBlocking) == hipSuccess &&
+                 hipEventCreateWithFlags(&n->ev_side0[k], hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&n->ev_side1[k], hipEventDisableTiming) == hipSuccess;
+        if (want && rc == GRL_OK && !ok) rc = nfail(n, GRL_E_HIP, "creating the index side streams failed");
+        n->idx_side = ok ? 1 : 0;
+    }
     if (rc == GRL_OK && hipFuncSetAttribute((const void *)expand_conv2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int)EXP2_LDS_BYTES) != hipSuccess)
         rc = nfail(n, GRL_E_HIP, "hipFuncSetAttribute(expand_conv2_kernel)");
@@ -1085,6 +1103,11 @@ int grl_net_destroy(grl_net *n) {
     for (int k = 1; k < GRL_MAX_LANES; ++k) {
         if (n->lane_stream[k]) { hipStreamSynchronize(n->lane_stream[k]); hipStreamDestroy(n->lane_stream[k]); }
         if (n->ev_join[k]) hipEventDestroy(n->ev_join[k]);
+    }
+    for (int k = 0; k < GRL_MAX_LANES; ++k) {
+        if (n->side_stream[k]) { hipStreamSynchronize(n->side_stream[k]); hipStreamDestroy(n->side_stream[k]); }
+        if (n->ev_side0[k]) hipEventDestroy(n->ev_side0[k]);
+        if (n->ev_side1[k]) hipEventDestroy(n->ev_side1[k]);
     }
     if (n->ev_fork) hipEventDestroy(n->ev_fork);
     if (n->ar_ev0) { hipEventDestroy(n->ar_ev0); hipEventDestroy(n->ar_ev1); }
