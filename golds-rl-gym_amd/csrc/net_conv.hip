@@ -214,8 +214,8 @@ struct grl_net : NetLane {
     // launches, each a dependent step of a few us) run on a side stream per lane beside the env-level trunk (net_shared.inc,
     // forward_conv12_shared): with one chunk per step -- 4 096 or 8 192 envs per GPU -- nothing else hides them (round 5).
     hipStream_t side_stream[GRL_MAX_LANES];
-    hipEvent_t ev_side0[GRL_MAX_LANES], ev_side1[GRL_MAX_LANES];
-    int idx_side;
+    hipEvent_t ev_side0[GRL_MAX_LANES], ev_side1[GRL_MAX_LANES], ev_side2[GRL_MAX_LANES];
+    int idx_side, pitem_on_side;
     int nlanes, cur_lane, last_lane;
 };
 
@@ -767,6 +767,7 @@ static int forward_chunk(grl_net *net, const uint8_t *lb, const uint8_t *ab, con
     const float *P = net->params, *PT = net->paramsT;
     const int n = nenv * 10;
     net->last_n = n;
+    net->pitem_on_side = 0;
     if (net->shared_trunk) {
         // gradient step on resident activations: at level 2 the trunk tensors are resident too, only the group sort reruns
         int rc;
@@ -779,7 +780,7 @@ static int forward_chunk(grl_net *net, const uint8_t *lb, const uint8_t *ab, con
             if (net->trunk_skip && net->expand2_gemm && (rc = trunk_index(net, lb, ab, pos, nenv))) return rc;      // the gradient step's row lists
             rc = patch_sort(net, n);
         } else {
-            rc = forward_conv12_shared(net, lb, ab, pos, nenv);
+            rc = forward_conv12_shared(net, lb, ab, pos, nenv, !reuse_tail);
         }
         if (rc) return rc;
     } else {
@@ -997,8 +998,8 @@ int grl_net_create(grl_handle *h, const grl_net_config *cfg, grl_net **out) {
     n->keep = nullptr; n->keep_slots = 0; n->param_version = 0; n->keep_version = -1;
     n->shared_trunk = (cfg->reserved & GRL_NET_F_PER_AGENT_TRUNK) ? 0 : 1;     // the plain per-agent evaluation is the A/B reference
     n->cur_lane = 0; n->last_lane = 0;
-    for (int k = 0; k < GRL_MAX_LANES; ++k) { n->lane_stream[k] = nullptr; n->ev_join[k] = nullptr; n->side_stream[k] = nullptr; n->ev_side0[k] = n->ev_side1[k] = nullptr; }
-    n->idx_side = 0;
+    for (int k = 0; k < GRL_MAX_LANES; ++k) { n->lane_stream[k] = nullptr; n->ev_join[k] = nullptr; n->side_stream[k] = nullptr; n->ev_side0[k] = n->ev_side1[k] = n->ev_side2[k] = nullptr; }
+    n->idx_side = 0; n->pitem_on_side = 0;
     n->lane_stream[0] = h->stream; n->ev_fork = nullptr; n->nlanes = 1;
     const size_t c = n->chunk;
     n->ptiles = (int)((c + 255) / 256) + 9;
@@ -1072,7 +1073,8 @@ int grl_net_create(grl_handle *h, const grl_net_config *cfg, grl_net **out) {
         for (int k = 0; k < nlanes && ok; ++k)
             ok = hipStreamCreateWithFlags(&n->side_stream[k], hipStreamNonBlocking) == hipSuccess &&
                  hipEventCreateWithFlags(&n->ev_side0[k], hipEventDisableTiming) == hipSuccess &&
-                 hipEventCreateWithFlags(&n->ev_side1[k], hipEventDisableTiming) == hipSuccess;
+                 hipEventCreateWithFlags(&n->ev_side1[k], hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&n->ev_side2[k], hipEventDisableTiming) == hipSuccess;
         if (want && rc == GRL_OK && !ok) rc = nfail(n, GRL_E_HIP, "creating the index side streams failed");
         n->idx_side = ok ? 1 : 0;
     }
@@ -1108,6 +1110,7 @@ int grl_net_destroy(grl_net *n) {
         if (n->side_stream[k]) { hipStreamSynchronize(n->side_stream[k]); hipStreamDestroy(n->side_stream[k]); }
         if (n->ev_side0[k]) hipEventDestroy(n->ev_side0[k]);
         if (n->ev_side1[k]) hipEventDestroy(n->ev_side1[k]);
+        if (n->ev_side2[k]) hipEventDestroy(n->ev_side2[k]);
     }
     if (n->ev_fork) hipEventDestroy(n->ev_fork);
     if (n->ar_ev0) { hipEventDestroy(n->ar_ev0); hipEventDestroy(n->ar_ev1); }
