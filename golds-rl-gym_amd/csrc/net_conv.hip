@@ -215,7 +215,7 @@ struct grl_net : NetLane {
     // forward_conv12_shared): with one chunk per step -- 4 096 or 8 192 envs per GPU -- nothing else hides them (round 5).
     hipStream_t side_stream[GRL_MAX_LANES];
     hipEvent_t ev_side0[GRL_MAX_LANES], ev_side1[GRL_MAX_LANES], ev_side2[GRL_MAX_LANES];
-    int idx_side, pitem_on_side;
+    int idx_side, side_now, pitem_on_side;      // side_now: set by grl_net_rollout while it enqueues a one-chunk-per-step rollout
     int nlanes, cur_lane, last_lane;
 };
 
@@ -957,6 +957,48 @@ static int ensure_tmp_obs(grl_net *net, int n_envs) {
 
 using namespace grl;
 
+// a workgroup that waits `ticks` of the 100 MHz constant clock (side_stream_pick)
+__global__ void grl_wait_kernel(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+// picks a stream that runs BESIDE lane 0 (see grl_net_create) into n->side_stream[0], or leaves it null
+static int side_stream_pick(grl_net *n) {
+    hipStream_t lane = n->lane_stream[0];
+    hipEvent_t e0 = nullptr, e1 = nullptr, ec = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventCreateWithFlags(&ec, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        return GRL_E_HIP;
+    }
+    const long long ticks = 6000;      // 60 us
+    hipStream_t cand[5] = {};
+    int pick = -1;
+    for (int c = 0; c < 5 && pick < 0; ++c) {
+        if (hipStreamCreateWithFlags(&cand[c], hipStreamNonBlocking) != hipSuccess) { cand[c] = nullptr; break; }
+        float best = 1e9f;
+        for (int rep = 0; rep < 3; ++rep) {      // the shortest of three: a wait can only be lengthened by others' work
+            (void)hipStreamSynchronize(lane);
+            (void)hipStreamSynchronize(cand[c]);
+            (void)hipEventRecord(e0, lane);
+            hipLaunchKernelGGL(grl_wait_kernel, dim3(1), dim3(64), 0, lane, ticks);
+            hipLaunchKernelGGL(grl_wait_kernel, dim3(1), dim3(64), 0, cand[c], ticks);
+            (void)hipEventRecord(ec, cand[c]);
+            (void)hipStreamWaitEvent(lane, ec, 0);
+            (void)hipEventRecord(e1, lane);
+            (void)hipStreamSynchronize(lane);
+            float ms = 1e9f;
+            if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms < best) best = ms;
+        }
+        if (best < 0.095f) pick = c;      // 60 us side by side; 120 one behind the other
+    }
+    for (int c = 0; c < 5; ++c)
+        if (cand[c] && c != pick) { (void)hipStreamSynchronize(cand[c]); (void)hipStreamDestroy(cand[c]); }
+    if (pick >= 0) n->side_stream[0] = cand[pick];
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(ec);
+    (void)hipGetLastError();
+    return GRL_OK;
+}
+
 extern "C" {
 
 int grl_net_config_default(int32_t kind, grl_net_config *cfg) {
@@ -999,7 +1041,7 @@ int grl_net_create(grl_handle *h, const grl_net_config *cfg, grl_net **out) {
     n->shared_trunk = (cfg->reserved & GRL_NET_F_PER_AGENT_TRUNK) ? 0 : 1;     // the plain per-agent evaluation is the A/B reference
     n->cur_lane = 0; n->last_lane = 0;
     for (int k = 0; k < GRL_MAX_LANES; ++k) { n->lane_stream[k] = nullptr; n->ev_join[k] = nullptr; n->side_stream[k] = nullptr; n->ev_side0[k] = n->ev_side1[k] = n->ev_side2[k] = nullptr; }
-    n->idx_side = 0; n->pitem_on_side = 0;
+    n->idx_side = 0; n->side_now = 0; n->pitem_on_side = 0;
     n->lane_stream[0] = h->stream; n->ev_fork = nullptr; n->nlanes = 1;
     const size_t c = n->chunk;
     n->ptiles = (int)((c + 255) / 256) + 9;
@@ -1066,17 +1108,24 @@ int grl_net_create(grl_handle *h, const grl_net_config *cfg, grl_net **out) {
         if (!ok) rc = nfail(n, GRL_E_HIP, "creating the lane streams/events failed");
     }
     if (rc == GRL_OK) n->nlanes = nlanes;
-    {   // the index side streams (not in the single-stream profiling configuration; GRL_NET_IDX_SIDE=off: everything on the lane's stream)
+    // The index side stream of lane 0 (used by a rollout with ONE chunk per step: grl_net_rollout; not in the single-stream profiling
+    // configuration; GRL_NET_IDX_SIDE=off: never).  It must sit on ANOTHER hardware queue than lane 0: the runtime deals the streams of
+    // a process onto four queues by their use counts, so after other handles and nets have come and gone a new stream may land on
+    // the lane's own queue -- the side work then serialises with the lane and the events cost on top (49.3 instead of 43.4 ms per
+    // 4 096-env update inside bench.py's shard leg, where lane 0 and its side stream shared queue 3; without it 45.7).  The HIP API does
+    // not name a stream's queue, so up to five candidates are TIMED against the lane -- two 60 us waits side by side take 60 us on two
+    // queues and 120 on one -- and the first that runs beside it is kept.  (Streams of another priority, or more than four queues,
+    // are no way out: kernels of extra queues of one process interleave with ~40 us per 5 us kernel: 72 and 61 ms.)
+    {
         const char *e = getenv("GRL_NET_IDX_SIDE");
-        const bool want = !(cfg->reserved & GRL_NET_F_SINGLE_STREAM) && !(e && (!strcmp(e, "off") || !strcmp(e, "0")));
-        bool ok = want && rc == GRL_OK;
-        for (int k = 0; k < nlanes && ok; ++k)
-            ok = hipStreamCreateWithFlags(&n->side_stream[k], hipStreamNonBlocking) == hipSuccess &&
-                 hipEventCreateWithFlags(&n->ev_side0[k], hipEventDisableTiming) == hipSuccess &&
-                 hipEventCreateWithFlags(&n->ev_side1[k], hipEventDisableTiming) == hipSuccess &&
-                 hipEventCreateWithFlags(&n->ev_side2[k], hipEventDisableTiming) == hipSuccess;
-        if (want && rc == GRL_OK && !ok) rc = nfail(n, GRL_E_HIP, "creating the index side streams failed");
-        n->idx_side = ok ? 1 : 0;
+        const bool want = !(cfg->reserved & GRL_NET_F_SINGLE_STREAM) && !(e && (!strcmp(e, "off") || !strcmp(e, "0"))) && rc == GRL_OK;
+        if (want && side_stream_pick(n) == GRL_OK && n->side_stream[0]) {
+            const bool ok = hipEventCreateWithFlags(&n->ev_side0[0], hipEventDisableTiming) == hipSuccess &&
+                            hipEventCreateWithFlags(&n->ev_side1[0], hipEventDisableTiming) == hipSuccess &&
+                            hipEventCreateWithFlags(&n->ev_side2[0], hipEventDisableTiming) == hipSuccess;
+            n->idx_side = ok ? 1 : 0;
+        }
+        (void)hipGetLastError();
     }
     if (rc == GRL_OK && hipFuncSetAttribute((const void *)expand_conv2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int)EXP2_LDS_BYTES) != hipSuccess)
