@@ -700,6 +700,41 @@ def test_resident_rollout_activations_equal_recomputation():
     assert np.abs(out[0][0][0]).max() > 0
 
 
+def test_the_index_side_stream_changes_nothing_but_the_timeline(monkeypatch):
+    """A rollout with ONE chunk per step (<= 8 192 envs per GPU: the strong-scaling shard, paac.py:302-387) enqueues the forward pass's
+    position-only index kernels -- slot lists, class / slot / patch sorts, the conv3 gather's item sort -- on a side stream of lane 0
+    beside the env-level trunk (round 5; net_shared.inc forward_conv12_shared).  Same kernels on the same buffers, ordered by events:
+    the rollout's actions, values, returns, the env state it leaves and the whole gradient must be EQUAL with and without it, over
+    several steps (the lists of step t are rewritten in step t + 1 while step t's consumers may still be queued) and two updates."""
+    from goldsrl import _ffi, _ffi_net
+    E, T = 200, 4
+    flat = _ffi_net.glorot_uniform_flat(seed=9)
+    res = {}
+    for mode in ("on", "off"):
+        monkeypatch.setenv("GRL_NET_IDX_SIDE", mode)      # read when the net is created
+        eng = _ffi.Engine(_ffi.ENV_SWARM, E, seed=41)
+        eng.reset()
+        net = _ffi_net.ConvNet(eng)      # one 2 000-sample chunk per step
+        net.set_params(flat)
+        out = []
+        for _ in range(2):
+            net.rollout(T, 0)
+            eng.wait()
+            acts = net.read_rollout("actions", (T, E * 10, 2)).copy()
+            vals = net.read_rollout("values", (T, E * 10)).copy()
+            adv = net.read_rollout("adv", (T, E * 10)).copy()
+            st = net.train_rollout(1e-3)
+            out.append((acts, vals, adv, net.get_grads().copy(), net.get_params().copy(), st, eng.get_state("SWARM_X").copy()))
+        res[mode] = out
+        net.close()
+        eng.close()
+    for a, b in zip(res["on"], res["off"]):
+        for x, y in zip(a[:5], b[:5]):
+            assert np.array_equal(x, y)
+        assert a[5] == b[5] and np.array_equal(a[6], b[6])
+    assert np.isfinite(res["on"][1][3]).all() and np.abs(res["on"][1][3]).max() > 0
+
+
 def test_full_size_forward_is_invariant_to_batch_position():
     """BASELINE size (32 768 envs = 327 680 agent-samples, 8 chunks on 4 streams): a sample's outputs do not depend on
     which chunk, stream, group tile or row it lands in -- re-evaluating 300 randomly picked envs as their own small batch
