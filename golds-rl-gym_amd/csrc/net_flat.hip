@@ -186,8 +186,8 @@ struct grl_fnet {
     bool ro_graph_ep;              // the captured rollout contains the R6 accounting launches
     int fast_forward;              // 1: synthesized-window forwards use net_flat_fast.inc (GRL_FLAT_FORWARD=layers: the layer-by-layer form)
     int ro_persistent;             // 1: the T-step actor loop is ONE persistent kernel (net_flat_rollout.inc); 0: the hipGraph of launches
-    size_t ro_lds_set;             // dynamic LDS size the rollout kernel's attribute is set to
-    void *d_roargs;                // RolloutArgs of the persistent rollout, in device memory
+    size_t ro_lds_set[3];          // dynamic LDS size the rollout kernel's attribute is set to (instances G = 16, 32, 64)
+    int ro_group;                  // envs per workgroup of the persistent rollout; 0: by the env count (GRL_FLAT_GROUP)
     int arg_slot;                  // this net's slot of g_flat_args (net_flat_fast.inc), -1: none free (graph path)
     long long *d_ts;               // stage timestamps of workgroup 0 of the persistent rollout (debug: grl_fnet_rollout_stage_times)
     int *d_ts_n;
@@ -404,12 +404,22 @@ static int launch_persistent_rollout(grl_fnet *net, int T) {
     const int n_assets = solow ? 0 : h->cfg.n_assets;
     const size_t lds_bytes = (size_t)rollout_lds_floats(net->cfg.static_size, T, n_assets, &R) * sizeof(float);
     if (lds_bytes > 160 * 1024) return GRL_E_SIZE;
-    if (lds_bytes > net->ro_lds_set) {
-        if (hipFuncSetAttribute((const void *)flat_rollout_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) {
+    // envs per workgroup: a workgroup has a CU to itself (LDS), and a group's chain of stages is as long for 16 envs as for 64 with
+    // fewer tiles per stage -- so small groups while every CU gets at most one workgroup (GRL_FLAT_GROUP = 64 / 32 / 16 fixes it).
+    // Measured (tools/flat_group_sweep.py, ms per 20-step rollout, G = 64 / 32 / 16): Solow 1 024 envs 0.99 / 0.66 / 0.62,
+    // 4 096: 1.00 / 0.75 / 0.86, 8 192: 1.09 / 0.89 / 1.66; TradeAR1-16 1 024: 1.99 / 1.50 / 1.40, 4 096: 2.02 / 1.61 / 1.67,
+    // 8 192: 2.09 / 1.79 / 3.27, 16 384: 2.20 / 3.51 / 6.47 -- groups of 16 pay once more than 64 of them run at once.
+    int G = net->ro_group;
+    if (!G) G = h->E <= 16 * 64 ? 16 : (h->E <= 32 * 256 ? 32 : 64);
+    R.gs = G;
+    const void *kern = G == 16 ? (const void *)flat_rollout_kernel<16> : (G == 32 ? (const void *)flat_rollout_kernel<32> : (const void *)flat_rollout_kernel<64>);
+    size_t &lds_set = net->ro_lds_set[G == 16 ? 0 : (G == 32 ? 1 : 2)];
+    if (lds_bytes > lds_set) {
+        if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) {
             (void)hipGetLastError();
             return GRL_E_SIZE;
         }
-        net->ro_lds_set = lds_bytes;
+        lds_set = lds_bytes;
     }
     if (solow) {
         R.so = solow_params(h);
@@ -430,15 +440,15 @@ static int launch_persistent_rollout(grl_fnet *net, int T) {
     R.ts = net->d_ts; R.ts_n = net->d_ts_n;
     if (net->d_ts_n) FNET_HIP(net, hipMemsetAsync(net->d_ts_n, 0, sizeof(int), st));
     FNET_HIP(net, hipMemsetAsync(h->done_count, 0, sizeof(int32_t), st));      // the last step's done list is built inside the kernel
-    if (!net->d_roargs) {
-        FNET_HIP(net, hipMalloc(&net->d_roargs, sizeof(RolloutArgs)));
-        net->allocs.push_back(net->d_roargs);
-    }
-    FNET_HIP(net, hipMemcpyAsync(net->d_roargs, &R, sizeof(RolloutArgs), hipMemcpyHostToDevice, st));      // pageable source: staged before the call returns
+    FNET_HIP(net, hipMemcpyToSymbolAsync(HIP_SYMBOL(g_ro_args), &R, sizeof(RolloutArgs), (size_t)net->arg_slot * sizeof(RolloutArgs),
+                                         hipMemcpyHostToDevice, st));      // pageable source: staged before the call returns
     FNET_HIP(net, hipMemcpyToSymbolAsync(HIP_SYMBOL(g_flat_args), &R.f, sizeof(FlatArgs), (size_t)net->arg_slot * sizeof(FlatArgs),
                                          hipMemcpyHostToDevice, st));
     (void)hipGetLastError();      // the symbol lookup may probe other ordinals and leave a stale error on this thread
-    hipLaunchKernelGGL(flat_rollout_kernel, dim3((h->E + 63) / 64), dim3(FNT), lds_bytes, st, (const RolloutArgs *)net->d_roargs);
+    const dim3 grid((h->E + G - 1) / G);
+    if (G == 16) hipLaunchKernelGGL(flat_rollout_kernel<16>, grid, dim3(FNT), lds_bytes, st, net->arg_slot);
+    else if (G == 32) hipLaunchKernelGGL(flat_rollout_kernel<32>, grid, dim3(FNT), lds_bytes, st, net->arg_slot);
+    else hipLaunchKernelGGL(flat_rollout_kernel<64>, grid, dim3(FNT), lds_bytes, st, net->arg_slot);
     FNET_HIP(net, hipGetLastError());
     return GRL_OK;
 }
@@ -488,7 +498,10 @@ int grl_fnet_create(grl_handle *h, const grl_fnet_config *cfg, grl_fnet **out) {
     {   // GRL_FLAT_ROLLOUT=graph keeps the launch-per-stage rollout (captured into a hipGraph) for A/B and for the equality tests
         const char *e = getenv("GRL_FLAT_ROLLOUT");
         n->ro_persistent = (e && strcmp(e, "graph") == 0) ? 0 : 1;
-        n->ro_lds_set = 0; n->d_ts = nullptr; n->d_ts_n = nullptr; n->d_roargs = nullptr;
+        n->ro_lds_set[0] = n->ro_lds_set[1] = n->ro_lds_set[2] = 0; n->d_ts = nullptr; n->d_ts_n = nullptr;
+        const char *g = getenv("GRL_FLAT_GROUP");
+        const int gv = g ? atoi(g) : 0;
+        n->ro_group = (gv == 16 || gv == 32 || gv == 64) ? gv : 0;
         n->arg_slot = flat_slot_take();
         const char *f = getenv("GRL_FLAT_FORWARD");
         n->fast_forward = (f && strcmp(f, "layers") == 0) ? 0 : 1;

@@ -200,14 +200,19 @@ def test_trade_rollout_with_the_a3c_workers_gae():
         _ffi_flat.FlatNet(eng, static_size=S, temporal_size=S, rnn_length=R, num_actions=n, gae_lambda=0.0)
 
 
-def _flat_job(kind, E, T, cap, mode, monkeypatch):
-    """One engine + FlatNet + three rollouts (with R6 accounting on); mode 'graph' keeps the launch-per-stage rollout."""
+def _flat_job(kind, E, T, cap, mode, monkeypatch, group=None):
+    """One engine + FlatNet + three rollouts (with R6 accounting on); mode 'graph' keeps the launch-per-stage rollout; group: the
+    persistent kernel's envs per workgroup (GRL_FLAT_GROUP; None = chosen by the env count)."""
     from goldsrl import _ffi
     from goldsrl import rollout as R
     if mode == "graph":
         monkeypatch.setenv("GRL_FLAT_ROLLOUT", "graph")
     else:
         monkeypatch.delenv("GRL_FLAT_ROLLOUT", raising=False)
+    if group is None:
+        monkeypatch.delenv("GRL_FLAT_GROUP", raising=False)
+    else:
+        monkeypatch.setenv("GRL_FLAT_GROUP", str(group))
     if kind == "solow":
         eng = _ffi.Engine(_ffi.ENV_SOLOW, E, seed=21, max_episode_steps=cap, solow_tape_len=64)
     else:
@@ -245,20 +250,22 @@ def _flat_job(kind, E, T, cap, mode, monkeypatch):
 
 @pytest.mark.parametrize("kind,E,cap", [("solow", 200, 7), ("solow", 4096, 1024), ("trade", 200, 9), ("trade", 1000, 1024)])
 def test_persistent_rollout_is_bit_identical_to_the_graph_of_launches(kind, E, cap, monkeypatch):
-    """The T-step actor loop as ONE kernel (a workgroup keeps 64 envs for the whole rollout) against the launch-per-stage
-    rollout it replaces: every rollout buffer, the env state, the handle's outputs, the done list and the R6 records, over three
-    consecutive rollouts with TimeLimit resets (and Solow tape refills) inside them; E = 200 leaves the last group partial."""
+    """The T-step actor loop as ONE kernel (a workgroup keeps a group of 64, 32 or 16 envs for the whole rollout: all three
+    instances, and the one the env count picks) against the launch-per-stage rollout it replaces: every rollout buffer, the env
+    state, the handle's outputs, the done list and the R6 records, over three consecutive rollouts with TimeLimit resets (and Solow
+    tape refills) inside them; E = 200 and E = 1000 leave the last group partial at every group size."""
     T = 20
-    a, pa = _flat_job(kind, E, T, cap, "persistent", monkeypatch)
     b, pb = _flat_job(kind, E, T, cap, "graph", monkeypatch)
-    for u, (da, db) in enumerate(zip(a, b)):
-        assert sorted(da) == sorted(db)
-        for k in da:
-            assert np.array_equal(da[k], db[k]), (kind, u, k)
-    for k in pa:
-        assert np.array_equal(pa[k], pb[k])
-    if cap < 20:      # episodes ended inside the rollouts: resets, tape refills and R6 records were exercised
-        assert sum(len(d["recs"]) for d in a) >= 2 * E
+    for group in (64, 32, 16, None):
+        a, pa = _flat_job(kind, E, T, cap, "persistent", monkeypatch, group)
+        for u, (da, db) in enumerate(zip(a, b)):
+            assert sorted(da) == sorted(db)
+            for k in da:
+                assert np.array_equal(da[k], db[k]), (kind, group, u, k)
+        for k in pa:
+            assert np.array_equal(pa[k], pb[k])
+        if cap < 20:      # episodes ended inside the rollouts: resets, tape refills and R6 records were exercised
+            assert sum(len(d["recs"]) for d in a) >= 2 * E
 
 
 @pytest.mark.parametrize("kind", ["solow", "trade"])
