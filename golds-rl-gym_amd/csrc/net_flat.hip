@@ -68,6 +68,7 @@ __host__ __device__ inline WsOff ws_offsets(int T, int A) {
 
 struct FlatArgs {
     const float *P;
+    const float *PT;                // backward only: every [K][N] weight matrix as [N][K] at the same offset (flat_transpose_kernel)
     FOff o;
     int n, S0, D, T, A;
     float scale, bound;
@@ -91,6 +92,30 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 #include "net_flat_fast.inc"
 #include "net_flat_bwd_fast.inc"
 #include "net_flat_rollout.inc"
+
+// PT: the weight matrices the data gradients multiply with, transposed (block b = matrix b; the GRU kernels: their recurrent rows)
+__global__ void flat_transpose_kernel(const float *__restrict__ P, float *__restrict__ PT, FOff o, int D, int A) {
+    long off;
+    int K, N;
+    switch (blockIdx.x) {
+        case 0: off = o.m1w; K = 3 * FH; N = 2 * FH; break;
+        case 1: off = o.g1w; K = 3 * FH; N = 2 * FH; break;
+        case 2: off = o.v1w; K = 3 * FH; N = 2 * FH; break;
+        case 3: off = o.m2w; K = 2 * FH; N = FH; break;
+        case 4: off = o.g2w; K = 2 * FH; N = FH; break;
+        case 5: off = o.m3w; K = FH; N = A; break;
+        case 6: off = o.g3w; K = FH; N = A; break;
+        case 7: off = o.tw; K = FH; N = 2 * FH; break;
+        case 8: off = o.s2w; K = 2 * FH; N = FH; break;
+        case 9: off = o.cw + (long)D * FH; K = FH; N = FH; break;
+        default: off = o.gw + (long)D * 2 * FH; K = FH; N = 2 * FH; break;
+    }
+    for (int e = threadIdx.x; e < K * N; e += blockDim.x) {
+        const int i = e / N, c = e - i * N;
+        PT[off + (long)c * K + i] = P[off + e];
+    }
+}
+constexpr int kFlatTransposed = 11;
 
 __global__ void flat_slab_reduce_kernel(const float *__restrict__ slab, int blocks, long n, float *__restrict__ dst) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -169,7 +194,7 @@ struct grl_fnet {
     std::string err;
     grl::FOff off;
     grl::WsOff wso;
-    float *params, *grads, *adam_m, *adam_v;
+    float *params, *paramsT, *grads, *adam_m, *adam_v;      // paramsT: net_flat_bwd_fast.inc (fb_dx)
     long adam_t;
     float *ws, *slab, *stats;
     double *stats64;
@@ -268,6 +293,9 @@ static int train_grads_device(grl_fnet *net, int n, const float *states, const f
     FlatArgs a = base_args(net, n, states, hist, net->mu, net->sigma, net->vs, true, nhist);
     a.actions = actions; a.adv = adv; a.y = y; a.inv_n = 1.0f / (float)n; a.slab = net->slab; a.stats64 = net->stats64;
     if (fast && net->arg_slot >= 0) {
+        a.PT = net->paramsT;
+        hipLaunchKernelGGL(flat_transpose_kernel, dim3(kFlatTransposed), dim3(256), 0, st, net->params, net->paramsT, net->off,
+                           net->cfg.temporal_size, net->cfg.num_actions);
         // the stages of the fast backward are calls that read their arguments from the net's __constant__ slot (net_flat_fast.inc)
         FNET_HIP(net, hipMemcpyToSymbolAsync(HIP_SYMBOL(g_flat_args), &a, sizeof(FlatArgs), (size_t)net->arg_slot * sizeof(FlatArgs),
                                              hipMemcpyHostToDevice, st));
@@ -488,7 +516,7 @@ int grl_fnet_create(grl_handle *h, const grl_fnet_config *cfg, grl_fnet **out) {
     const int A = cfg->num_actions, S0 = cfg->static_size, D = cfg->temporal_size, T = cfg->rnn_length;
     int rc = GRL_OK;
     auto Al = [&](float **p, size_t cnt) { if (rc == GRL_OK) rc = falloc(n, p, cnt); };
-    Al(&n->params, n->off.total); Al(&n->grads, n->off.total); Al(&n->adam_m, n->off.total); Al(&n->adam_v, n->off.total);
+    Al(&n->params, n->off.total); Al(&n->paramsT, n->off.total); Al(&n->grads, n->off.total); Al(&n->adam_m, n->off.total); Al(&n->adam_v, n->off.total);
     Al(&n->ws, ms * n->wso.total); Al(&n->slab, (size_t)n->slab_blocks * n->off.total); Al(&n->stats, 8);
     Al(&n->d_states, ms * S0); Al(&n->d_hist, ms * T * D); Al(&n->d_act, ms * A); Al(&n->d_adv, ms); Al(&n->d_y, ms);
     Al(&n->mu, ms * A); Al(&n->sigma, ms * A); Al(&n->vs, ms);
