@@ -248,7 +248,7 @@ def spread(per_s):
 
 def flat_config_block(kind, E, T, device_id, steps=10):
     """BASELINE configs[1] (Solow-v0, 4 096 envs) / the per-GPU share of configs[4] (TradeAR1 n=16, 65 536 envs / 8 GPUs = 8 192)
-    with FlatPolicyVNetwork (GRU(32) + MLP): the T-step PAAC rollout as ONE persistent kernel (a workgroup keeps 64 envs for all
+    with FlatPolicyVNetwork (GRU(32) + MLP): the T-step PAAC rollout as ONE persistent kernel (a workgroup keeps 64 / 32 / 16 envs for all
     T steps: forward, sample, env step, auto-reset, bookkeeping, returns -- csrc/net_flat_rollout.inc) + the gradient step, timed
     here so the numbers are driver-visible.  These shapes are LATENCY bound: a step moves E x 53 B (Solow) / E x 481 B
     (TradeAR1-16) of env state and ~45 kMAC per sample through 2 x rnn + 5 dependent stages of one workgroup per CU; a bandwidth
@@ -275,7 +275,7 @@ def flat_config_block(kind, E, T, device_id, steps=10):
                 # rollout: done-count memset + argument upload x2 + ONE kernel; update: forward, two memsets, backward, slab reduce,
                 # sum of squares, finalize, Adam
                 "dependent_launches_per_update": 4 + 8,
-                "rollout_kernel": "flat_rollout_kernel (persistent: one workgroup of 16 waves per 64 envs for all T steps)",
+                "rollout_kernel": "flat_rollout_kernel<G> (persistent: one workgroup of 16 waves per G envs for all T steps; G = 16 up to 1 024 envs, 32 up to 8 192, else 64)",
                 "env_bytes_per_update": E * T * bytes_per_env_step,
                 "note": "value = rollout + loss/backward/clip/Adam; %d KB of env traffic per step against ~%d us per step: not "
                         "bandwidth bound at this size" % (E * bytes_per_env_step // 1024, int(out["ms_per_rollout"] * 1e3 / (T + 1)))})

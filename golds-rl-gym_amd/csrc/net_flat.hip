@@ -122,25 +122,40 @@ __global__ void flat_transpose_kernel(const float *__restrict__ P, float *__rest
 }
 constexpr int kFlatTransposed = 11;
 
-__global__ void flat_slab_reduce_kernel(const float *__restrict__ slab, int blocks, long n, float *__restrict__ dst) {
-    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+// dst[i] = sum over the workgroups' slabs, in a fixed order: 64 parameters per block, thread (q, p) adds the slabs q, q + 16, ..
+// for parameter p (16 loads in flight per parameter instead of one thread walking all 256 slabs), the 16 partial sums then in order
+__global__ __launch_bounds__(1024) void flat_slab_reduce_kernel(const float *__restrict__ slab, int blocks, long n, float *__restrict__ dst) {
+    __shared__ float part[16][64];
+    const int p = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const long i = (long)blockIdx.x * 64 + p;
     float s = 0.f;
-    for (int b = 0; b < blocks; ++b) s += slab[(long)b * n + i];
-    dst[i] = s;
+    if (i < n)
+        for (int b = q; b < blocks; b += 16) s += slab[(long)b * n + i];
+    part[q][p] = s;
+    __syncthreads();
+    if (q == 0 && i < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += part[k][p];
+        dst[i] = t;
+    }
 }
 
+// sum of squares in float64: kSumsqBlocks partial sums (a contiguous slice each, tree inside the block), added up in order by
+// flat_finalize_kernel
+constexpr int kSumsqBlocks = 32;
 __global__ __launch_bounds__(256) void flat_sumsq_kernel(const float *__restrict__ g, long n, double *__restrict__ out) {
     __shared__ double red[256];
+    const long per = (n + kSumsqBlocks - 1) / kSumsqBlocks, lo = (long)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
     double s = 0.0;
-    for (long i = threadIdx.x; i < n; i += 256) s += (double)g[i] * (double)g[i];
+    for (long i = lo + threadIdx.x; i < hi; i += 256) s += (double)g[i] * (double)g[i];
     red[threadIdx.x] = s;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
         if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[0] = red[0];
+    if (threadIdx.x == 0) out[blockIdx.x] = red[0];
 }
 
 // grad_scale: 1/world after a sum over ranks (the loss is a mean over the WHOLE batch, policy_v_network.py:246-251); the norm and
@@ -148,7 +163,9 @@ __global__ __launch_bounds__(256) void flat_sumsq_kernel(const float *__restrict
 __global__ void flat_finalize_kernel(const double *__restrict__ sumsq, const double *__restrict__ stats64, float inv_n, float inv_na,
                                      float clip_norm, float grad_scale, float *__restrict__ stats) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    float norm = (float)(sqrt(sumsq[0]) * (double)grad_scale);
+    double ss = 0.0;
+    for (int b = 0; b < kSumsqBlocks; ++b) ss += sumsq[b];
+    float norm = (float)(sqrt(ss) * (double)grad_scale);
     float pl = (float)(stats64[0] * (double)inv_na), cl = (float)(stats64[1] * (double)inv_n);
     stats[0] = pl; stats[1] = cl; stats[2] = pl + cl; stats[3] = norm;
     stats[4] = grad_scale * (clip_norm > 0.f ? clip_norm / fmaxf(norm, clip_norm) : 1.0f);      // tf.clip_by_global_norm
@@ -293,7 +310,7 @@ static int train_grads_device(grl_fnet *net, int n, const float *states, const f
     const bool fast = nhist && net->cfg.static_size == net->cfg.temporal_size && net->fast_forward && net->arg_slot >= 0;
     int blocks = groups < net->slab_blocks ? groups : net->slab_blocks;
     if (fast && blocks > 256) blocks = 256;      // the 16-wave form: one workgroup per CU (100 KB of LDS)
-    FNET_HIP(net, hipMemsetAsync(net->slab, 0, (size_t)blocks * net->off.total * 4, st));
+    if (!fast) FNET_HIP(net, hipMemsetAsync(net->slab, 0, (size_t)blocks * net->off.total * 4, st));      // the fast backward clears its own
     FNET_HIP(net, hipMemsetAsync(net->stats64, 0, 4 * sizeof(double), st));
     FlatArgs a = base_args(net, n, states, hist, net->mu, net->sigma, net->vs, true, nhist);
     a.actions = actions; a.adv = adv; a.y = y; a.inv_n = 1.0f / (float)n; a.slab = net->slab; a.stats64 = net->stats64;
@@ -309,7 +326,7 @@ static int train_grads_device(grl_fnet *net, int n, const float *states, const f
     } else {
         hipLaunchKernelGGL(flat_backward_kernel, dim3(blocks), dim3(256), FLAT_LDS_BYTES, st, a);
     }
-    hipLaunchKernelGGL(flat_slab_reduce_kernel, dim3((unsigned)((net->off.total + 255) / 256)), dim3(256), 0, st, net->slab, blocks,
+    hipLaunchKernelGGL(flat_slab_reduce_kernel, dim3((unsigned)((net->off.total + 63) / 64)), dim3(1024), 0, st, net->slab, blocks,
                        net->off.total, net->grads);
     FNET_HIP(net, hipGetLastError());
     net->last_n = n;
@@ -337,8 +354,8 @@ static int fcomm_allreduce_grads(grl_fnet *net, float *grad_scale_out) {
 static int train_apply_device(grl_fnet *net, float lr, int apply_update, float grad_scale, float *stats_host) {
     hipStream_t st = net->h->stream;
     const int n = net->last_n;
-    hipLaunchKernelGGL(flat_sumsq_kernel, dim3(1), dim3(256), 0, st, net->grads, net->off.total, net->stats64 + 2);
-    hipLaunchKernelGGL(flat_finalize_kernel, dim3(1), dim3(64), 0, st, net->stats64 + 2, net->stats64, 1.0f / (float)n,
+    hipLaunchKernelGGL(flat_sumsq_kernel, dim3(kSumsqBlocks), dim3(256), 0, st, net->grads, net->off.total, net->stats64 + 4);
+    hipLaunchKernelGGL(flat_finalize_kernel, dim3(1), dim3(64), 0, st, net->stats64 + 4, net->stats64, 1.0f / (float)n,
                        1.0f / ((float)n * (float)net->cfg.num_actions), net->cfg.clip_norm, grad_scale, net->stats);
     if (apply_update) {
         net->adam_t += 1;
@@ -525,7 +542,7 @@ int grl_fnet_create(grl_handle *h, const grl_fnet_config *cfg, grl_fnet **out) {
     Al(&n->ws, (ms + 63) / 64 * 64 * n->wso.total); Al(&n->slab, (size_t)n->slab_blocks * n->off.total); Al(&n->stats, 8);
     Al(&n->d_states, ms * S0); Al(&n->d_hist, ms * T * D); Al(&n->d_act, ms * A); Al(&n->d_adv, ms); Al(&n->d_y, ms);
     Al(&n->mu, ms * A); Al(&n->sigma, ms * A); Al(&n->vs, ms);
-    if (rc == GRL_OK) rc = falloc(n, &n->stats64, 8);
+    if (rc == GRL_OK) rc = falloc(n, &n->stats64, 4 + kSumsqBlocks);      // loss sums (2 used of 4), then the squares' partial sums
     if (rc == GRL_OK) rc = falloc(n, &n->d_counter, 4);
     n->ro_graph = nullptr; n->ro_graph_T = 0; n->ro_graph_ep = false;
     {   // GRL_FLAT_ROLLOUT=graph keeps the launch-per-stage rollout (captured into a hipGraph) for A/B and for the equality tests
