@@ -233,8 +233,10 @@ struct grl_fnet {
     bool ro_graph_ep;              // the captured rollout contains the R6 accounting launches
     int fast_forward;              // 1: synthesized-window forwards use net_flat_fast.inc (GRL_FLAT_FORWARD=layers: the layer-by-layer form)
     int ro_persistent;             // 1: the T-step actor loop is ONE persistent kernel (net_flat_rollout.inc); 0: the hipGraph of launches
-    size_t ro_lds_set[3];          // dynamic LDS size the rollout kernel's attribute is set to (instances G = 16, 32, 64)
+    size_t ro_lds_set[2][3];       // dynamic LDS size the rollout kernel's attribute is set to (instances KEEP x G = 16, 32, 64)
     int ro_group;                  // envs per workgroup of the persistent rollout; 0: by the env count (GRL_FLAT_GROUP)
+    int keep_activations;          // grl_fnet_set_keep_activations: the persistent rollout fills the training workspace
+    int ws_resident;               // the workspace holds the forward of the last rollout's T x E samples under the CURRENT parameters
     int arg_slot;                  // this net's slot of g_flat_args (net_flat_fast.inc), -1: none free (graph path)
     long long *d_ts;               // stage timestamps of workgroup 0 of the persistent rollout (debug: grl_fnet_rollout_stage_times)
     int *d_ts_n;
@@ -300,11 +302,17 @@ static int launch_forward(grl_fnet *net, int n, const float *states, const float
 }
 
 // forward(save) + backward over n device-resident samples; grads <- gradient of the mean loss over THESE n samples
+// resident: the workspace already holds this forward (the rollout that produced the samples kept its activations, and the
+// parameters have not moved since): the pass starts at the backward
 static int train_grads_device(grl_fnet *net, int n, const float *states, const float *hist, const float *actions, const float *adv,
-                              const float *y, const int32_t *nhist = nullptr) {
+                              const float *y, const int32_t *nhist = nullptr, bool resident = false) {
     hipStream_t st = net->h->stream;
     if (n > net->cfg.max_samples) return ffail(net, GRL_E_SIZE, "train: n exceeds max_samples of the net");
-    int rc = launch_forward(net, n, states, hist, net->mu, net->sigma, net->vs, true, nhist);
+    int rc = GRL_OK;
+    if (!resident) {
+        net->ws_resident = 0;
+        rc = launch_forward(net, n, states, hist, net->mu, net->sigma, net->vs, true, nhist);
+    }
     if (rc) return rc;
     int groups = (n + 63) / 64;
     const bool fast = nhist && net->cfg.static_size == net->cfg.temporal_size && net->fast_forward && net->arg_slot >= 0;
@@ -358,6 +366,7 @@ static int train_apply_device(grl_fnet *net, float lr, int apply_update, float g
     hipLaunchKernelGGL(flat_finalize_kernel, dim3(1), dim3(64), 0, st, net->stats64 + 4, net->stats64, 1.0f / (float)n,
                        1.0f / ((float)n * (float)net->cfg.num_actions), net->cfg.clip_norm, grad_scale, net->stats);
     if (apply_update) {
+        net->ws_resident = 0;      // the parameters move
         net->adam_t += 1;
         float lr_t = (float)((double)lr * sqrt(1.0 - pow(0.999, (double)net->adam_t)) / (1.0 - pow(0.9, (double)net->adam_t)));
         hipLaunchKernelGGL(flat_adam_kernel, dim3((unsigned)((net->off.total + 255) / 256)), dim3(256), 0, st, net->params, net->grads,
@@ -380,8 +389,8 @@ static int train_apply_device(grl_fnet *net, float lr, int apply_update, float g
 
 // gradient pass [+ all-reduce over ranks if a communicator is attached and the parameters are to be updated] + clip + Adam
 static int train_device(grl_fnet *net, int n, const float *states, const float *hist, const float *actions, const float *adv, const float *y,
-                        float lr, int apply_update, float *stats_host, const int32_t *nhist = nullptr) {
-    int rc = train_grads_device(net, n, states, hist, actions, adv, y, nhist);
+                        float lr, int apply_update, float *stats_host, const int32_t *nhist = nullptr, bool resident = false) {
+    int rc = train_grads_device(net, n, states, hist, actions, adv, y, nhist, resident);
     if (rc) return rc;
     float grad_scale = 1.0f;
     if (apply_update && (rc = fcomm_allreduce_grads(net, &grad_scale))) return rc;
@@ -450,6 +459,8 @@ static int launch_persistent_rollout(grl_fnet *net, int T) {
     const bool solow = h->cfg.env_kind == GRL_ENV_SOLOW;
     RolloutArgs R{};
     R.f = base_args(net, h->E, nullptr, nullptr, nullptr, nullptr, nullptr, false);
+    const bool keep = net->keep_activations != 0;
+    if (keep) R.f.ws = net->ws;
     R.steps = T; R.env_kind = h->cfg.env_kind; R.slot = net->arg_slot;
     const int n_assets = solow ? 0 : h->cfg.n_assets;
     const size_t lds_bytes = (size_t)rollout_lds_floats(net->cfg.static_size, T, n_assets, &R) * sizeof(float);
@@ -462,8 +473,13 @@ static int launch_persistent_rollout(grl_fnet *net, int T) {
     int G = net->ro_group;
     if (!G) G = h->E <= 16 * 64 ? 16 : (h->E <= 32 * 256 ? 32 : 64);
     R.gs = G;
-    const void *kern = G == 16 ? (const void *)flat_rollout_kernel<16> : (G == 32 ? (const void *)flat_rollout_kernel<32> : (const void *)flat_rollout_kernel<64>);
-    size_t &lds_set = net->ro_lds_set[G == 16 ? 0 : (G == 32 ? 1 : 2)];
+    typedef void (*RoKernel)(int);
+    static const RoKernel kernels[2][3] = {{flat_rollout_kernel<16, false>, flat_rollout_kernel<32, false>, flat_rollout_kernel<64, false>},
+                                           {flat_rollout_kernel<16, true>, flat_rollout_kernel<32, true>, flat_rollout_kernel<64, true>}};
+    const int gi = G == 16 ? 0 : (G == 32 ? 1 : 2);
+    const RoKernel kern_fn = kernels[keep ? 1 : 0][gi];
+    const void *kern = (const void *)kern_fn;
+    size_t &lds_set = net->ro_lds_set[keep ? 1 : 0][gi];
     if (lds_bytes > lds_set) {
         if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) {
             (void)hipGetLastError();
@@ -496,10 +512,9 @@ static int launch_persistent_rollout(grl_fnet *net, int T) {
                                          hipMemcpyHostToDevice, st));
     (void)hipGetLastError();      // the symbol lookup may probe other ordinals and leave a stale error on this thread
     const dim3 grid((h->E + G - 1) / G);
-    if (G == 16) hipLaunchKernelGGL(flat_rollout_kernel<16>, grid, dim3(FNT), lds_bytes, st, net->arg_slot);
-    else if (G == 32) hipLaunchKernelGGL(flat_rollout_kernel<32>, grid, dim3(FNT), lds_bytes, st, net->arg_slot);
-    else hipLaunchKernelGGL(flat_rollout_kernel<64>, grid, dim3(FNT), lds_bytes, st, net->arg_slot);
+    hipLaunchKernelGGL(kern_fn, grid, dim3(FNT), lds_bytes, st, net->arg_slot);
     FNET_HIP(net, hipGetLastError());
+    net->ws_resident = keep ? 1 : 0;
     return GRL_OK;
 }
 
@@ -548,7 +563,8 @@ int grl_fnet_create(grl_handle *h, const grl_fnet_config *cfg, grl_fnet **out) {
     {   // GRL_FLAT_ROLLOUT=graph keeps the launch-per-stage rollout (captured into a hipGraph) for A/B and for the equality tests
         const char *e = getenv("GRL_FLAT_ROLLOUT");
         n->ro_persistent = (e && strcmp(e, "graph") == 0) ? 0 : 1;
-        n->ro_lds_set[0] = n->ro_lds_set[1] = n->ro_lds_set[2] = 0; n->d_ts = nullptr; n->d_ts_n = nullptr;
+        memset(n->ro_lds_set, 0, sizeof(n->ro_lds_set)); n->d_ts = nullptr; n->d_ts_n = nullptr;
+        n->keep_activations = 0; n->ws_resident = 0;
         const char *g = getenv("GRL_FLAT_GROUP");
         const int gv = g ? atoi(g) : 0;
         n->ro_group = (gv == 16 || gv == 32 || gv == 64) ? gv : 0;
@@ -607,7 +623,16 @@ static int fcopy_flat(grl_fnet *n, float *dev, float *host, int64_t cnt, bool to
     else FNET_HIP(n, hipMemcpy(host, dev, cnt * 4, hipMemcpyDeviceToHost));
     return GRL_OK;
 }
-int grl_fnet_set_params(grl_fnet *n, const float *host, int64_t cnt) { return fcopy_flat(n, n ? n->params : nullptr, (float *)host, cnt, true); }
+int grl_fnet_set_params(grl_fnet *n, const float *host, int64_t cnt) {
+    if (n) n->ws_resident = 0;
+    return fcopy_flat(n, n ? n->params : nullptr, (float *)host, cnt, true);
+}
+
+int grl_fnet_set_keep_activations(grl_fnet *net, int32_t on) {
+    if (!net) return GRL_E_INVALID;
+    net->keep_activations = on ? 1 : 0;
+    return GRL_OK;
+}
 int grl_fnet_get_params(grl_fnet *n, float *host, int64_t cnt) { return fcopy_flat(n, n ? n->params : nullptr, host, cnt, false); }
 int grl_fnet_get_grads(grl_fnet *n, float *host, int64_t cnt) { return fcopy_flat(n, n ? n->grads : nullptr, host, cnt, false); }
 
@@ -724,6 +749,7 @@ int grl_fnet_rollout(grl_fnet *net, int32_t T) {
         if (rc) return rc;
     }
     net->T = T;
+    net->ws_resident = 0;      // set again by a persistent rollout that keeps its activations
     hipStream_t st = h->stream;
     // draw counter of step t = act_counter + t, read by the sample kernel from device memory
     FNET_HIP(net, hipMemsetD32Async((hipDeviceptr_t)net->d_counter, (int)(uint32_t)net->act_counter, 1, st));
@@ -791,7 +817,8 @@ int grl_fnet_train_rollout(grl_fnet *net, float lr, float *stats_host) {
     if (!net || !net->ro_states || net->T <= 0) return ffail(net, GRL_E_STATE, "grl_fnet_train_rollout: no rollout to train on");
     hipSetDevice(net->h->cfg.device_id);
     const int n = net->T * net->h->E;
-    return train_device(net, n, net->ro_states, nullptr, net->ro_act, net->ro_adv, net->ro_y, lr, 1, stats_host, net->ro_nhist);
+    return train_device(net, n, net->ro_states, nullptr, net->ro_act, net->ro_adv, net->ro_y, lr, 1, stats_host, net->ro_nhist,
+                        net->ws_resident != 0);
 }
 
 // the gradient step in two halves for callers that exchange gradients themselves (host all-reduce through gloo when no RCCL
@@ -800,7 +827,7 @@ int grl_fnet_train_rollout_grads(grl_fnet *net, float *stats_host) {
     if (!net || !net->ro_states || net->T <= 0) return ffail(net, GRL_E_STATE, "grl_fnet_train_rollout_grads: no rollout to train on");
     hipSetDevice(net->h->cfg.device_id);
     const int n = net->T * net->h->E;
-    int rc = train_grads_device(net, n, net->ro_states, nullptr, net->ro_act, net->ro_adv, net->ro_y, net->ro_nhist);
+    int rc = train_grads_device(net, n, net->ro_states, nullptr, net->ro_act, net->ro_adv, net->ro_y, net->ro_nhist, net->ws_resident != 0);
     if (rc) return rc;
     return train_apply_device(net, 0.f, 0, 1.0f, stats_host);
 }

@@ -31,6 +31,7 @@ FNET_SIGNATURES = {
     "grl_fnet_predict_env": (C.c_int, [_P, _P, _P, _P]),
     "grl_fnet_train": (C.c_int, [_P, _I, _P, _P, _P, _P, _P, _F, _I, _P]),
     "grl_fnet_rollout": (C.c_int, [_P, _I]),
+    "grl_fnet_set_keep_activations": (C.c_int, [_P, _I]),
     "grl_fnet_train_rollout": (C.c_int, [_P, _F, _P]),
     "grl_fnet_read_rollout": (C.c_int, [_P, C.c_char_p, _P, _SZ]),
     "grl_fnet_train_rollout_grads": (C.c_int, [_P, _P]),
@@ -178,6 +179,11 @@ class FlatNet(object):
 
     def rollout(self, T):
         self._check(self.lib.grl_fnet_rollout(self.n, T))
+
+    def set_keep_activations(self, on):
+        """The rollouts that follow fill the training workspace; train_rollout on them starts at the backward pass (bit-identical
+        gradients, the rollout pays the stores).  Off by default."""
+        self._check(self.lib.grl_fnet_set_keep_activations(self.n, 1 if on else 0))
 
     def train_rollout(self, lr):
         stats = np.zeros(4, np.float32)

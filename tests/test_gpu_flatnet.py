@@ -268,6 +268,56 @@ def test_persistent_rollout_is_bit_identical_to_the_graph_of_launches(kind, E, c
             assert sum(len(d["recs"]) for d in a) >= 2 * E
 
 
+@pytest.mark.parametrize("kind,E", [("solow", 200), ("solow", 1100), ("trade", 200), ("trade", 1100)])
+def test_a_rollout_that_keeps_its_activations_trains_exactly_as_one_that_recomputes_them(kind, E, monkeypatch):
+    """grl_fnet_set_keep_activations: the persistent rollout fills the training workspace (step-major samples t * E + env, written by
+    workgroups of 16 / 32 envs that share the 64-sample blocks of the layout) and the gradient step starts at the backward pass.
+    Against the gradient step that runs its own forward: the local gradient of a first pass, then parameters, statistics and the next
+    rollout's buffers over three updates -- bitwise (the loss statistics to 1e-6: atomics).  A keep-rollout whose parameters were replaced before training must not use
+    what it kept."""
+    from goldsrl import _ffi
+    from goldsrl import rollout as R
+    T = 6
+    res = {}
+    for keep in ("1", "0"):
+        monkeypatch.setenv("GRL_FLAT_KEEP", keep)
+        monkeypatch.delenv("GRL_FLAT_ROLLOUT", raising=False)
+        monkeypatch.delenv("GRL_FLAT_GROUP", raising=False)
+        if kind == "solow":
+            eng = _ffi.Engine(_ffi.ENV_SOLOW, E, seed=5, max_episode_steps=4)
+        else:
+            eng = _ffi.Engine(_ffi.ENV_TRADE, E, seed=5, n_assets=16, rnn_length=20, max_episode_steps=4)
+        eng.reset()
+        roll = R.FlatPolicyRollout(eng, T, train=True, lr=1e-3)
+        assert roll.keep_activations == (keep == "1")
+        out = []
+        roll.net.set_keep_activations(roll.keep_activations)
+        roll.net.rollout(T); eng.wait()
+        roll.net.train_rollout_grads()
+        out.append(roll.net.get_grads())
+        for _ in range(3):
+            roll.run(); eng.wait()
+            out.append(np.array([roll.last_stats[k] for k in ("loss", "policy_loss", "critic_loss_mean", "global_norm")]))
+            out.append(roll.net.get_params())
+            out.append(roll.net.read_rollout("values", (T, E)))
+        # parameters replaced between a keep-rollout and its gradient step: the kept activations are stale
+        roll.net.set_keep_activations(roll.keep_activations)
+        roll.net.rollout(T); eng.wait()
+        p = roll.net.get_params()
+        roll.net.set_params((p * 1.01).astype(np.float32))
+        roll.net.train_rollout_grads()
+        out.append(roll.net.get_grads())
+        res[keep] = out
+        roll.net.close(); eng.close()
+    assert len(res["1"]) == len(res["0"])
+    for i, (x, y) in enumerate(zip(res["1"], res["0"])):
+        if x.shape == (4,):      # the loss statistics: float64 atomics over the workgroups, in whatever order they finish
+            np.testing.assert_allclose(x, y, rtol=1e-6)
+        else:
+            assert np.array_equal(x, y), (kind, E, i)
+    assert np.abs(res["1"][0]).max() > 0
+
+
 @pytest.mark.parametrize("kind", ["solow", "trade"])
 def test_fast_forward_form_equals_the_layer_by_layer_form(kind, monkeypatch):
     """net_flat_fast.inc (2T + 5 stages: input halves of the GRU GEMMs hoisted out of the time loop, fused epilogues, merged
