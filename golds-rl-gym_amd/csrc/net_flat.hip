@@ -755,8 +755,10 @@ int grl_fnet_rollout(grl_fnet *net, int32_t T) {
     FNET_HIP(net, hipMemsetD32Async((hipDeviceptr_t)net->d_counter, (int)(uint32_t)net->act_counter, 1, st));
     net->act_counter += (unsigned long)T;
     // one workgroup per 64 envs and one workgroup per CU (its LDS): beyond two rounds of workgroups (E > 32 768) the graph of
-    // launches, whose forward runs two workgroups per CU, is faster (measured at 65 536 TradeAR1 envs: 16.7 vs 22.7 ms)
-    if (net->ro_persistent && (E + 63) / 64 <= 512) {
+    // launches takes over.  Measured at the end of round 5, persistent / graph, ms per 20-step rollout: TradeAR1-16 32 768 envs
+    // 3.86 / 4.40, 65 536: 7.64 / 7.84; Solow 32 768: 2.01 / 1.93, 65 536: 3.94 / 3.39 (GRL_FLAT_PERSIST_GROUPS moves the limit)
+    static const int persist_max_groups = getenv("GRL_FLAT_PERSIST_GROUPS") ? atoi(getenv("GRL_FLAT_PERSIST_GROUPS")) : 512;
+    if (net->ro_persistent && (E + 63) / 64 <= persist_max_groups) {
         rc = launch_persistent_rollout(net, T);
         if (rc == GRL_OK) { h->step_in_flight = true; return GRL_OK; }
         if (rc != GRL_E_SIZE) return rc;
