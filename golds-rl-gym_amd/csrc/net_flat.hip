@@ -287,7 +287,8 @@ static int launch_forward(grl_fnet *net, int n, const float *states, const float
     const int groups = (n + 63) / 64;
     if (nhist && net->cfg.static_size == net->cfg.temporal_size && net->fast_forward) {
         // synthesized window (the PAAC worker's: the current state repeated): the 2T + 5 stage form of net_flat_fast.inc
-        hipLaunchKernelGGL(flat_forward_fast_kernel, dim3(groups), dim3(FNT), ff_lds_bytes(net->cfg.static_size), net->h->stream, a);
+        if (save) hipLaunchKernelGGL(flat_forward_fast_kernel<true>, dim3(groups), dim3(FNT), ff_lds_bytes(net->cfg.static_size), net->h->stream, a);
+        else hipLaunchKernelGGL(flat_forward_fast_kernel<false>, dim3(groups), dim3(FNT), ff_lds_bytes(net->cfg.static_size), net->h->stream, a);
         FNET_HIP(net, hipGetLastError());
         return GRL_OK;
     }
@@ -582,7 +583,9 @@ int grl_fnet_create(grl_handle *h, const grl_fnet_config *cfg, grl_fnet **out) {
     if (rc == GRL_OK && e == hipSuccess)
         e = hipFuncSetAttribute((const void *)flat_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLAT_LDS_BYTES);
     if (rc == GRL_OK && e == hipSuccess)
-        e = hipFuncSetAttribute((const void *)flat_forward_fast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ff_lds_bytes(MAXS0));
+        e = hipFuncSetAttribute((const void *)flat_forward_fast_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ff_lds_bytes(MAXS0));
+    if (rc == GRL_OK && e == hipSuccess)
+        e = hipFuncSetAttribute((const void *)flat_forward_fast_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ff_lds_bytes(MAXS0));
     if (rc == GRL_OK && e == hipSuccess)
         e = hipFuncSetAttribute((const void *)flat_backward_fast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FB2_LDS_BYTES);
     if (rc == GRL_OK && e != hipSuccess) rc = ffail(n, GRL_E_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
