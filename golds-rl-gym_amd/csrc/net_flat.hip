@@ -881,6 +881,7 @@ int grl_fnet_comm_info(grl_fnet *net, int32_t *count_out, int32_t *user_rank_out
 int grl_fnet_comm_broadcast_params(grl_fnet *net, int32_t root) {
     if (!net || !net->comm) return ffail(net, GRL_E_STATE, "grl_fnet_comm_broadcast_params: no communicator");
     hipSetDevice(net->h->cfg.device_id);
+    net->ws_resident = 0;      // the parameters may move (every rank but the root)
     ncclResult_t r = ncclBroadcast(net->params, net->params, (size_t)net->off.total, ncclFloat, root, (ncclComm_t)net->comm, net->h->stream);
     (void)hipGetLastError();
     if (r != ncclSuccess) return ffail(net, GRL_E_COMM, std::string("ncclBroadcast: ") + ncclGetErrorString(r));
