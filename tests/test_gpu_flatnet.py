@@ -268,8 +268,9 @@ def test_persistent_rollout_is_bit_identical_to_the_graph_of_launches(kind, E, c
             assert sum(len(d["recs"]) for d in a) >= 2 * E
 
 
-@pytest.mark.parametrize("kind,E", [("solow", 200), ("solow", 1100), ("trade", 200), ("trade", 1100)])
-def test_a_rollout_that_keeps_its_activations_trains_exactly_as_one_that_recomputes_them(kind, E, monkeypatch):
+@pytest.mark.parametrize("kind,E,group", [("solow", 200, None), ("solow", 1100, None), ("trade", 200, None), ("trade", 1100, None),
+                                           ("solow", 300, 64), ("trade", 300, 64)])
+def test_a_rollout_that_keeps_its_activations_trains_exactly_as_one_that_recomputes_them(kind, E, group, monkeypatch):
     """grl_fnet_set_keep_activations: the persistent rollout fills the training workspace (step-major samples t * E + env, written by
     workgroups of 16 / 32 envs that share the 64-sample blocks of the layout) and the gradient step starts at the backward pass.
     Against the gradient step that runs its own forward: the local gradient of a first pass, then parameters, statistics and the next
@@ -282,7 +283,10 @@ def test_a_rollout_that_keeps_its_activations_trains_exactly_as_one_that_recompu
     for keep in ("1", "0"):
         monkeypatch.setenv("GRL_FLAT_KEEP", keep)
         monkeypatch.delenv("GRL_FLAT_ROLLOUT", raising=False)
-        monkeypatch.delenv("GRL_FLAT_GROUP", raising=False)
+        if group is None:      # 16 envs per workgroup at E = 200, 32 at 1 100; 64 (what more than 8 192 envs get) is forced
+            monkeypatch.delenv("GRL_FLAT_GROUP", raising=False)
+        else:
+            monkeypatch.setenv("GRL_FLAT_GROUP", str(group))
         if kind == "solow":
             eng = _ffi.Engine(_ffi.ENV_SOLOW, E, seed=5, max_episode_steps=4)
         else:
@@ -314,7 +318,7 @@ def test_a_rollout_that_keeps_its_activations_trains_exactly_as_one_that_recompu
         if x.shape == (4,):      # the loss statistics: float64 atomics over the workgroups, in whatever order they finish
             np.testing.assert_allclose(x, y, rtol=1e-6)
         else:
-            assert np.array_equal(x, y), (kind, E, i)
+            assert np.array_equal(x, y), (kind, E, group, i)
     assert np.abs(res["1"][0]).max() > 0
 
 
