@@ -233,7 +233,7 @@ struct grl_fnet {
     bool ro_graph_ep;              // the captured rollout contains the R6 accounting launches
     int fast_forward;              // 1: synthesized-window forwards use net_flat_fast.inc (GRL_FLAT_FORWARD=layers: the layer-by-layer form)
     int ro_persistent;             // 1: the T-step actor loop is ONE persistent kernel (net_flat_rollout.inc); 0: the hipGraph of launches
-    size_t ro_lds_set[2][3];       // dynamic LDS size the rollout kernel's attribute is set to (instances KEEP x G = 16, 32, 64)
+    char ro_attr_set[2][3];        // the rollout kernel instance (KEEP x G = 16, 32, 64) has its dynamic-LDS limit raised on this net's device
     int ro_group;                  // envs per workgroup of the persistent rollout; 0: by the env count (GRL_FLAT_GROUP)
     int keep_activations;          // grl_fnet_set_keep_activations: the persistent rollout fills the training workspace
     int ws_resident;               // the workspace holds the forward of the last rollout's T x E samples under the CURRENT parameters
@@ -480,13 +480,15 @@ static int launch_persistent_rollout(grl_fnet *net, int T) {
     const int gi = G == 16 ? 0 : (G == 32 ? 1 : 2);
     const RoKernel kern_fn = kernels[keep ? 1 : 0][gi];
     const void *kern = (const void *)kern_fn;
-    size_t &lds_set = net->ro_lds_set[keep ? 1 : 0][gi];
-    if (lds_bytes > lds_set) {
-        if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) {
+    // the attribute belongs to the kernel (per device), not to the net: every net raises it to the CU's whole LDS, so that no net's
+    // smaller rollout lowers it under another net's larger one
+    char &attr_set = net->ro_attr_set[keep ? 1 : 0][gi];
+    if (!attr_set) {
+        if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
             (void)hipGetLastError();
             return GRL_E_SIZE;
         }
-        lds_set = lds_bytes;
+        attr_set = 1;
     }
     if (solow) {
         R.so = solow_params(h);
@@ -564,7 +566,7 @@ int grl_fnet_create(grl_handle *h, const grl_fnet_config *cfg, grl_fnet **out) {
     {   // GRL_FLAT_ROLLOUT=graph keeps the launch-per-stage rollout (captured into a hipGraph) for A/B and for the equality tests
         const char *e = getenv("GRL_FLAT_ROLLOUT");
         n->ro_persistent = (e && strcmp(e, "graph") == 0) ? 0 : 1;
-        memset(n->ro_lds_set, 0, sizeof(n->ro_lds_set)); n->d_ts = nullptr; n->d_ts_n = nullptr;
+        memset(n->ro_attr_set, 0, sizeof(n->ro_attr_set)); n->d_ts = nullptr; n->d_ts_n = nullptr;
         n->keep_activations = 0; n->ws_resident = 0;
         const char *g = getenv("GRL_FLAT_GROUP");
         const int gv = g ? atoi(g) : 0;
