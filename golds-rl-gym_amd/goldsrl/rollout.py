@@ -70,13 +70,11 @@ class FlatPolicyRollout(_GradientExchange):
         self.net.set_params(_ffi_flat.default_init_flat(seed, static_size=sizes["static_size"], temporal_size=sizes["temporal_size"],
                                                         num_actions=sizes["num_actions"]))
         self.last_stats = None
-        # A rollout that is trained on can keep its activations for the gradient step instead of recomputing them there.  Measured
-        # (tools/flat_update_times.py, ms per update, recompute -> keep): TradeAR1-16, rnn 20, 8 192 envs 3.78 -> 3.21; Solow, rnn 5,
-        # 4 096 envs 1.25 -> 1.29 (the stores inside its 2 x 5 recurrent stages cost more than 5 rounds of a 33 us forward save):
-        # on for long windows.  GRL_FLAT_KEEP=0 / 1 forces it (the A/B switch and the equality test).
+        # A rollout that is trained on keeps its activations for the gradient step instead of recomputing them there.  Measured
+        # (tools/flat_keep_cost.py, ms rollout + gradient step, recompute -> keep): TradeAR1-16, rnn 20, 8 192 envs 1.28 + 2.31 -> 1.44 + 1.43;
+        # Solow, rnn 5, 4 096 envs 0.51 + 0.72 -> 0.59 + 0.50.  GRL_FLAT_KEEP=0 / 1 forces it (the A/B switch and the equality test).
         import os
-        k = os.environ.get("GRL_FLAT_KEEP")
-        self.keep_activations = (k != "0") if k is not None else net_kw["rnn_length"] >= 10
+        self.keep_activations = os.environ.get("GRL_FLAT_KEEP", "1") != "0"
 
     def run(self):
         # a rollout that is trained on keeps its activations for the gradient step (GRL_FLAT_KEEP=0: recompute them, the A/B switch)

@@ -75,8 +75,8 @@ int grl_fnet_rollout(grl_fnet *net, int32_t T);
 /* on != 0: the rollouts that follow (persistent-kernel form) also fill the net's training workspace with every layer's
  * activations of their T x num_envs forwards, and grl_fnet_train_rollout / _grads on such a rollout start at the backward pass --
  * what the reference's train step recomputes (policy_v_network.py:246-264 on the batch paac.py:178-186 stacks) is the same
- * parameters on the same inputs.  Bit-identical gradients; the rollout pays the stores (off by default: a rollout nobody trains on
- * should not).  Anything that moves the parameters or overwrites the workspace in between falls back to the recomputation. */
+ * parameters on the same inputs.  Bit-identical gradients; the rollout pays the stores (+14 % at rnn 5 and 20; off by default: a rollout nobody
+ * trains on should not).  Anything that moves the parameters or overwrites the workspace in between falls back to the recomputation. */
 int grl_fnet_set_keep_activations(grl_fnet *net, int32_t on);
 /* Gradient step on the last rollout: [all-reduce over ranks if a communicator is attached], clip, Adam. */
 int grl_fnet_train_rollout(grl_fnet *net, float lr, float *stats_host);
