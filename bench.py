@@ -276,7 +276,7 @@ def flat_config_block(kind, E, T, device_id, steps=10):
                 # activations: windows of >= 10 rows), a memset, weight transposes, backward, slab reduce, sum of squares, finalize, Adam
                 "dependent_launches_per_update": 4 + 8,
                 "rollout_keeps_activations": bool(roll.keep_activations),
-                "rollout_kernel": "flat_rollout_kernel<G> (persistent: one workgroup of 16 waves per G envs for all T steps; G = 16 up to 1 024 envs, 32 up to 8 192, else 64)",
+                "rollout_kernel": "flat_rollout_kernel<G> (persistent: one workgroup of 16 waves per G envs for all T steps; G = 16 up to 4 096 envs, 32 up to 8 192, else 64)",
                 "env_bytes_per_update": E * T * bytes_per_env_step,
                 "note": "value = rollout + loss/backward/clip/Adam; %d KB of env traffic per step against ~%d us per step: not "
                         "bandwidth bound at this size" % (E * bytes_per_env_step // 1024, int(out["ms_per_rollout"] * 1e3 / (T + 1)))})

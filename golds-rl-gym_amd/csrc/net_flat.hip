@@ -467,12 +467,13 @@ static int launch_persistent_rollout(grl_fnet *net, int T) {
     const size_t lds_bytes = (size_t)rollout_lds_floats(net->cfg.static_size, T, n_assets, &R) * sizeof(float);
     if (lds_bytes > 160 * 1024) return GRL_E_SIZE;
     // envs per workgroup: a workgroup has a CU to itself (LDS), and a group's chain of stages is as long for 16 envs as for 64 with
-    // fewer tiles per stage -- so small groups while every CU gets at most one workgroup (GRL_FLAT_GROUP = 64 / 32 / 16 fixes it).
-    // Measured (tools/flat_group_sweep.py, ms per 20-step rollout, G = 64 / 32 / 16): Solow 1 024 envs 0.99 / 0.66 / 0.62,
-    // 4 096: 1.00 / 0.75 / 0.86, 8 192: 1.09 / 0.89 / 1.66; TradeAR1-16 1 024: 1.99 / 1.50 / 1.40, 4 096: 2.02 / 1.61 / 1.67,
-    // 8 192: 2.09 / 1.79 / 3.27, 16 384: 2.20 / 3.51 / 6.47 -- groups of 16 pay once more than 64 of them run at once.
+    // fewer tiles per stage -- so the smallest group that still gives every CU at most one workgroup (GRL_FLAT_GROUP = 64 / 32 / 16
+    // fixes it).  Measured at the end of round 5 (tools/flat_group_sweep.py, ms per 20-step rollout, G = 64 / 32 / 16): TradeAR1-16
+    // 1 024 envs 1.74 / 1.25 / 1.16, 4 096: 1.76 / 1.25 / 1.17, 8 192: 1.76 / 1.26 / 2.30, 16 384: 1.78 / 2.48 / 4.55; Solow 4 096:
+    // 0.79 / 0.51 / 0.48, 8 192: 0.80 / 0.51 / 0.91.  (While every forward call still moved 44 callee-saved registers through
+    // scratch, 256 workgroups at once were slower than 128 and groups of 16 paid only up to 1 024 envs.)
     int G = net->ro_group;
-    if (!G) G = h->E <= 16 * 64 ? 16 : (h->E <= 32 * 256 ? 32 : 64);
+    if (!G) G = h->E <= 16 * 256 ? 16 : (h->E <= 32 * 256 ? 32 : 64);
     R.gs = G;
     typedef void (*RoKernel)(int);
     static const RoKernel kernels[2][3] = {{flat_rollout_kernel<16, false>, flat_rollout_kernel<32, false>, flat_rollout_kernel<64, false>},

@@ -268,7 +268,7 @@ def test_persistent_rollout_is_bit_identical_to_the_graph_of_launches(kind, E, c
             assert sum(len(d["recs"]) for d in a) >= 2 * E
 
 
-@pytest.mark.parametrize("kind,E,group", [("solow", 200, None), ("solow", 1100, None), ("trade", 200, None), ("trade", 1100, None),
+@pytest.mark.parametrize("kind,E,group", [("solow", 200, None), ("solow", 1100, 32), ("trade", 200, None), ("trade", 1100, 32),
                                            ("solow", 300, 64), ("trade", 300, 64)])
 def test_a_rollout_that_keeps_its_activations_trains_exactly_as_one_that_recomputes_them(kind, E, group, monkeypatch):
     """grl_fnet_set_keep_activations: the persistent rollout fills the training workspace (step-major samples t * E + env, written by
@@ -283,7 +283,7 @@ def test_a_rollout_that_keeps_its_activations_trains_exactly_as_one_that_recompu
     for keep in ("1", "0"):
         monkeypatch.setenv("GRL_FLAT_KEEP", keep)
         monkeypatch.delenv("GRL_FLAT_ROLLOUT", raising=False)
-        if group is None:      # 16 envs per workgroup at E = 200, 32 at 1 100; 64 (what more than 8 192 envs get) is forced
+        if group is None:      # 16 envs per workgroup up to 4 096 envs; 32 (up to 8 192) and 64 (beyond) are forced
             monkeypatch.delenv("GRL_FLAT_GROUP", raising=False)
         else:
             monkeypatch.setenv("GRL_FLAT_GROUP", str(group))
